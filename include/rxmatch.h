@@ -1,0 +1,195 @@
+/*
+ * rxmatch.h — C-ABI drop-in boundary of the MI355X-native CSR-NFA matcher (librxmatch.so).
+ *
+ * Plain C: extern "C", plain pointers and sizes, no torch / C++ types.  Every entry point returns
+ * 0 (RX_OK) or a negative RX_E* code; rx_strerror() names it.  Nothing throws across the boundary.
+ *
+ * What each entry point replaces in the reference (paths under /root/reference):
+ *
+ *   rx_nfa_load_coe / rx_nfa_from_words
+ *        the Block-RAM initialisation of `design_1_wrapper` from Block_Mem/*.coe
+ *        (instantiated Simulation/testbench_BLK_Mem.sv:89-92, Design/top.v:10-13) plus the
+ *        `size` port / `size_range` parameter (Design/FPGA.v:26,46; testbench_BLK_Mem.sv:20,39).
+ *        The 128-bit lines are kept UNCHANGED as one u32 word array: row_ptr = W[0..size],
+ *        packed (symbol<<24|target) edges = W[size+1 ..] (FPGA.v:773,793,881-898).
+ *   rx_trace_load_mem
+ *        `$readmemh("input_trace_lo.mem", data_read_lo)` (testbench_BLK_Mem.sv:34-35).
+ *   rx_match / rx_plan_*
+ *        module CSR_traversal (Design/FPGA.v:23-43 ports, :115-768 per-clock active-state
+ *        update) driven by the byte feeder + match counters of Blk_Mem_tb
+ *        (testbench_BLK_Mem.sv:49-87): `input_char/input_char_2` become rows of `bytes`,
+ *        the `accepting_match_flag` pulses qualified by `i` become rx_event records /
+ *        match_count / the per-pass any-match bitmap.
+ *   rx_match_sharded
+ *        nothing in the reference (it has one device); contiguous stream blocks per GPU, no
+ *        collective.
+ *
+ * Pass indexing follows the reference: pass k examines the active set S_k (S_0 = {0}) while
+ * input byte c[k] is on `input_char`; an accept event (k, state) means `state` (a row with no
+ * out-edges, FPGA.v:210-226) was active in pass k, i.e. a match ENDED on byte c[k-1].
+ *   RX_MODE_FULL      passes k = 0 .. N      (N+1 passes; pass N only checks accepts)
+ *   RX_MODE_TB_COMPAT passes k = 0 .. N-2    (what Blk_Mem_tb observes before $finish,
+ *                                             testbench_BLK_Mem.sv:71-86)
+ *
+ * The product path is HIP only.  There is no CPU fallback: without a usable HIP device every
+ * compute entry point fails with RX_ENODEVICE.
+ */
+#ifndef RXMATCH_H
+#define RXMATCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RX_ABI_VERSION 1
+
+/* ---- error codes ------------------------------------------------------------------------ */
+enum {
+  RX_OK = 0,
+  RX_EINVAL = -1,    /* bad argument (NULL, zero size, stride < stream_len, ...) */
+  RX_EIO = -2,       /* file could not be opened / read */
+  RX_EFORMAT = -3,   /* .coe / .mem text is malformed */
+  RX_ENFA = -4,      /* word array is not a valid CSR automaton (row_ptr / targets / size) */
+  RX_ENOMEM = -5,    /* host or device allocation failed */
+  RX_ENODEVICE = -6, /* no usable HIP device (there is NO CPU fallback) */
+  RX_EHIP = -7,      /* a HIP runtime call failed; rx_last_hip_error() has the text */
+  RX_ECAPACITY = -8, /* automaton or batch exceeds a kernel limit */
+  RX_ESTATE = -9     /* plan used out of order (launch before input, download before launch) */
+};
+const char* rx_strerror(int code);
+/* Text of the last HIP failure on the calling thread ("" if none). */
+const char* rx_last_hip_error(void);
+int rx_abi_version(void);
+
+/* ---- automaton -------------------------------------------------------------------------- */
+typedef struct rx_nfa rx_nfa; /* immutable after load => rx_match is re-entrant per rx_nfa */
+
+typedef struct rx_nfa_info {
+  uint32_t size;        /* number of NFA states                                   */
+  uint32_t nnz;         /* number of edges = row_ptr[size]                        */
+  uint32_t n_accept;    /* states with an empty row (accept states)               */
+  uint32_t n_words;     /* u32 words in the table incl. 0-3 pad words             */
+  uint32_t max_degree;  /* longest row                                            */
+  uint32_t n_bitmask_words64; /* ceil(size/64): u64 words of one active-state bitmask */
+} rx_nfa_info;
+
+/* size_or_0 = 0 infers the state count from the table (unique s with W[0]=0, W[0..s]
+ * non-decreasing, 0 <= nwords-(W[s]+s+1) <= 3 zero pad words, all targets < s). */
+int rx_nfa_load_coe(const char* path, uint32_t size_or_0, rx_nfa** out);
+int rx_nfa_from_words(const uint32_t* words, size_t nwords, uint32_t size_or_0, rx_nfa** out);
+int rx_nfa_get_info(const rx_nfa* nfa, rx_nfa_info* info);
+/* The table exactly as it sits in HBM: row_ptr = words, edges = words + size + 1. */
+const uint32_t* rx_nfa_words(const rx_nfa* nfa, size_t* nwords);
+void rx_nfa_free(rx_nfa* nfa);
+
+/* ---- traces ----------------------------------------------------------------------------- */
+/* $readmemh text (one 1-2 digit hex byte per line) -> malloc'ed byte array; release with rx_free. */
+int rx_trace_load_mem(const char* path, uint8_t** bytes, size_t* n);
+void rx_free(void* p);
+
+/* ---- options / results ------------------------------------------------------------------ */
+enum { RX_MODE_FULL = 0, RX_MODE_TB_COMPAT = 1 };
+
+enum {
+  RX_KERNEL_AUTO = 0,     /* fastest parity-checked kernel for this automaton            */
+  RX_KERNEL_CSR_WAVE = 1, /* wavefront-per-stream over the state-major CSR as loaded     */
+  RX_KERNEL_SYM_WAVE = 2, /* wavefront-per-stream over the per-(state,symbol) slice index */
+  RX_KERNEL_SYM_GROUP = 3 /* 16-lane group per stream (4 streams per wavefront), slice index */
+};
+
+typedef struct rx_opts {
+  uint32_t struct_size; /* = sizeof(rx_opts); 0 is accepted as "this version"            */
+  int32_t device;       /* HIP device ordinal; -1 = the calling thread's current device  */
+  uint32_t mode;        /* RX_MODE_*                                                     */
+  uint32_t kernel;      /* RX_KERNEL_*                                                   */
+  void* stream;         /* hipStream_t to launch on; NULL = the default stream           */
+  uint64_t k_base;      /* added to every reported pass index (chunked streaming)        */
+  uint32_t collect_stats; /* !=0: also accumulate rx_stats.sum_active/sum_edges on device */
+  uint32_t reserved;
+} rx_opts;
+
+/* One accept pulse: `state` was active and accepting in pass `k` of stream `stream`.
+ * 12 bytes — the B_out event term of SURVEY.md §8(d). */
+typedef struct rx_event {
+  uint32_t stream;
+  uint32_t k;
+  uint32_t state;
+} rx_event;
+
+typedef struct rx_stats {
+  uint64_t n_passes;     /* passes executed per stream                                    */
+  uint64_t n_events;     /* accept events over all streams (may exceed events_cap)        */
+  uint64_t sum_active;   /* sum over passes of |S_k|        (collect_stats only, else 0)  */
+  uint64_t sum_edges;    /* sum over passes of sum deg(i)   (collect_stats only, else 0)  */
+  uint64_t alg_bytes;    /* passes*1 + 8*sum_active + 4*sum_edges +
+                            ceil(passes/8) + 12*n_events   (collect_stats only, else 0)   */
+  double kernel_ms;      /* hipEvent time of the match kernel(s) of the last launch       */
+  double h2d_ms, d2h_ms; /* hipEvent time of the copies rx_match() issued (0 for plans)   */
+  uint32_t kernel_used;  /* RX_KERNEL_* actually launched                                 */
+  uint32_t n_launches;
+} rx_stats;
+
+/* All output arrays are caller-allocated and optional (NULL = not wanted). */
+typedef struct rx_result {
+  uint32_t struct_size;      /* = sizeof(rx_result); 0 accepted                           */
+  uint32_t events_overflow;  /* out: 1 if n_events > events_cap (events[] holds the first
+                                events_cap in (stream,k,state) order of those captured)   */
+  rx_event* events;          /* [events_cap], returned sorted by (stream, k, state)       */
+  size_t events_cap;
+  size_t n_events;           /* out: events written (<= events_cap)                       */
+  uint32_t* match_count;     /* [n_streams][size]: pulses per state, full 32-bit; the
+                                testbench's 10-bit wrap (testbench_BLK_Mem.sv:21-22) is
+                                applied by the report tool, not here                      */
+  uint64_t* match_count_total; /* [size]: match_count summed over streams                 */
+  uint32_t* anymatch;        /* [n_streams][anymatch_stride]: bit k (word k>>5, bit k&31)
+                                set iff some accept state was active in pass k            */
+  size_t anymatch_stride;    /* in u32 words, >= ceil(n_passes/32)                        */
+  uint64_t* final_active;    /* [n_streams][ceil(size/64)]: S after the last pass's byte  */
+  rx_stats stats;            /* out */
+} rx_result;
+
+/* ---- one-shot match over host buffers ---------------------------------------------------- */
+/* bytes: n_streams rows of stream_len bytes, row s at bytes + s*stride.  init_active (optional,
+ * [n_streams][ceil(size/64)]) replaces the reset state S_0={0} (FPGA.v:134-147) per stream. */
+int rx_match(const rx_nfa* nfa, const uint8_t* bytes, size_t n_streams, size_t stream_len,
+             size_t stride, const uint64_t* init_active, const rx_opts* opts, rx_result* res);
+
+/* Same, streams split into contiguous blocks over n_devices GPUs (one host thread each, the
+ * table replicated per device, no collective).  devices == NULL => ordinals 0..n_devices-1. */
+int rx_match_sharded(const rx_nfa* nfa, const uint8_t* bytes, size_t n_streams, size_t stream_len,
+                     size_t stride, const int* devices, int n_devices, const rx_opts* opts,
+                     rx_result* res);
+
+/* ---- resident plan: inputs stay in HBM between launches (serving / benchmarking) --------- */
+typedef struct rx_plan rx_plan;
+
+int rx_plan_create(const rx_nfa* nfa, const rx_opts* opts, size_t max_streams,
+                   size_t max_stream_len, size_t events_cap, uint32_t want_match_count,
+                   uint32_t want_anymatch, uint32_t want_final, rx_plan** out);
+/* Copy host bytes into the plan's own HBM input buffer (row stride = stride). */
+int rx_plan_upload(rx_plan* plan, const uint8_t* bytes, size_t n_streams, size_t stream_len,
+                   size_t stride);
+/* Use a caller-owned DEVICE buffer as the input (e.g. a torch tensor's data_ptr). */
+int rx_plan_set_device_input(rx_plan* plan, const void* device_bytes, size_t n_streams,
+                             size_t stream_len, size_t stride);
+/* Optional per-stream start state (host array, copied to HBM); NULL restores reset. */
+int rx_plan_set_init_active(rx_plan* plan, const uint64_t* init_active);
+/* Enqueue result-reset + the match kernel on the plan's stream, bracketed by hipEvents. */
+int rx_plan_launch(rx_plan* plan);
+/* Wait for the last launch; kernel_ms (optional) = its hipEvent duration. */
+int rx_plan_sync(rx_plan* plan, double* kernel_ms);
+/* Copy the last launch's results to the caller's arrays (sorted events, counts, ...). */
+int rx_plan_download(rx_plan* plan, rx_result* res);
+void rx_plan_free(rx_plan* plan);
+
+/* ---- device helpers (so callers need no HIP binding of their own) ------------------------ */
+int rx_device_count(int* n);
+int rx_device_name(int device, char* buf, size_t buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RXMATCH_H */
