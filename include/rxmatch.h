@@ -7,7 +7,7 @@
  * What each entry point replaces in the reference (paths under /root/reference):
  *
  *   rx_nfa_load_coe / rx_nfa_from_words
- *        the Block-RAM initialisation of `design_1_wrapper` from Block_Mem/*.coe
+ *        the Block-RAM initialisation of `design_1_wrapper` from the Block_Mem .coe files
  *        (instantiated Simulation/testbench_BLK_Mem.sv:89-92, Design/top.v:10-13) plus the
  *        `size` port / `size_range` parameter (Design/FPGA.v:26,46; testbench_BLK_Mem.sv:20,39).
  *        The 128-bit lines are kept UNCHANGED as one u32 word array: row_ptr = W[0..size],

@@ -1,0 +1,597 @@
+// rx_api.cpp — the C-ABI of librxmatch.so (include/rxmatch.h): automaton handles, resident plans,
+// one-shot and multi-GPU sharded matching.  Host C++ over the HIP runtime; the only compute path is
+// the gfx950 kernels in rx_kernels.hip — there is no CPU fallback and no oracle code in here.
+//
+// Replaces Blk_Mem_tb's role (Simulation/testbench_BLK_Mem.sv:26-106): it owns the ROM image
+// (now an HBM buffer), feeds bytes (now whole resident batches), and collects the
+// accepting_match_flag pulses (now rx_event records, counters and bitmaps).
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "rx_internal.hpp"
+
+// ---- errors ---------------------------------------------------------------------------------------
+static thread_local std::string g_last_hip;
+
+static int hip_fail(hipError_t e, const char* what) {
+  g_last_hip = std::string(what) + ": " + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ")";
+  if (e == hipErrorNoDevice || e == hipErrorInsufficientDriver || e == hipErrorInvalidDevice ||
+      e == hipErrorNotInitialized || e == hipErrorInitializationError)
+    return RX_ENODEVICE;
+  if (e == hipErrorOutOfMemory) return RX_ENOMEM;
+  return RX_EHIP;
+}
+#define HIPCHK(call)                                           \
+  do {                                                         \
+    hipError_t e_ = (call);                                    \
+    if (e_ != hipSuccess) return hip_fail(e_, #call);          \
+  } while (0)
+
+extern "C" const char* rx_strerror(int code) {
+  switch (code) {
+    case RX_OK: return "ok";
+    case RX_EINVAL: return "invalid argument";
+    case RX_EIO: return "file could not be read";
+    case RX_EFORMAT: return "malformed .coe/.mem text";
+    case RX_ENFA: return "word array is not a valid CSR automaton";
+    case RX_ENOMEM: return "out of memory";
+    case RX_ENODEVICE: return "no usable HIP device (librxmatch has no CPU fallback)";
+    case RX_EHIP: return "HIP runtime error (see rx_last_hip_error)";
+    case RX_ECAPACITY: return "automaton or batch exceeds a kernel limit";
+    case RX_ESTATE: return "plan used out of order";
+    default: return "unknown error";
+  }
+}
+extern "C" const char* rx_last_hip_error(void) { return g_last_hip.c_str(); }
+extern "C" int rx_abi_version(void) { return RX_ABI_VERSION; }
+
+// ---- automaton ------------------------------------------------------------------------------------
+struct DevTables {
+  uint32_t* words = nullptr;
+  uint32_t* symidx = nullptr;
+  uint32_t* ovf = nullptr;
+  uint32_t* accept_bits = nullptr;
+  int cu_count = 0;
+  size_t lds_per_cu = 0;
+};
+
+struct rx_nfa {
+  RxHostNfa h;
+  std::mutex mu;
+  std::map<int, DevTables> dev;  // HBM copies, one per device, uploaded on first use
+};
+
+extern "C" int rx_nfa_from_words(const uint32_t* words, size_t nwords, uint32_t size_or_0, rx_nfa** out) {
+  if (!words || !out || nwords == 0) return RX_EINVAL;
+  rx_nfa* n = new (std::nothrow) rx_nfa();
+  if (!n) return RX_ENOMEM;
+  int rc = rxh_build(words, nwords, size_or_0, &n->h);
+  if (rc) { delete n; return rc; }
+  *out = n;
+  return RX_OK;
+}
+
+extern "C" int rx_nfa_load_coe(const char* path, uint32_t size_or_0, rx_nfa** out) {
+  if (!path || !out) return RX_EINVAL;
+  std::string txt;
+  int rc = rxh_read_file(path, &txt);
+  if (rc) return rc;
+  std::vector<uint32_t> w;
+  rc = rxh_parse_coe_text(txt.data(), txt.size(), &w);
+  if (rc) return rc;
+  return rx_nfa_from_words(w.data(), w.size(), size_or_0, out);
+}
+
+extern "C" int rx_nfa_get_info(const rx_nfa* nfa, rx_nfa_info* info) {
+  if (!nfa || !info) return RX_EINVAL;
+  info->size = nfa->h.size;
+  info->nnz = nfa->h.nnz;
+  info->n_accept = nfa->h.n_accept;
+  info->n_words = (uint32_t)nfa->h.words.size();
+  info->max_degree = nfa->h.max_degree;
+  info->n_bitmask_words64 = (nfa->h.size + 63u) / 64u;
+  return RX_OK;
+}
+
+extern "C" const uint32_t* rx_nfa_words(const rx_nfa* nfa, size_t* nwords) {
+  if (!nfa) return nullptr;
+  if (nwords) *nwords = nfa->h.words.size();
+  return nfa->h.words.data();
+}
+
+extern "C" void rx_nfa_free(rx_nfa* nfa) {
+  if (!nfa) return;
+  int prev = -1;
+  bool have_prev = hipGetDevice(&prev) == hipSuccess;
+  for (auto& kv : nfa->dev) {
+    if (hipSetDevice(kv.first) != hipSuccess) continue;
+    (void)hipFree(kv.second.words);
+    (void)hipFree(kv.second.symidx);
+    (void)hipFree(kv.second.ovf);
+    (void)hipFree(kv.second.accept_bits);
+  }
+  if (have_prev) (void)hipSetDevice(prev);
+  delete nfa;
+}
+
+extern "C" int rx_trace_load_mem(const char* path, uint8_t** bytes, size_t* n) {
+  if (!path || !bytes || !n) return RX_EINVAL;
+  std::string txt;
+  int rc = rxh_read_file(path, &txt);
+  if (rc) return rc;
+  std::vector<uint8_t> b;
+  rc = rxh_parse_mem_text(txt.data(), txt.size(), &b);
+  if (rc) return rc;
+  uint8_t* o = (uint8_t*)malloc(b.size() ? b.size() : 1);
+  if (!o) return RX_ENOMEM;
+  memcpy(o, b.data(), b.size());
+  *bytes = o;
+  *n = b.size();
+  return RX_OK;
+}
+extern "C" void rx_free(void* p) { free(p); }
+
+extern "C" int rx_device_count(int* n) {
+  if (!n) return RX_EINVAL;
+  *n = 0;
+  HIPCHK(hipGetDeviceCount(n));
+  return RX_OK;
+}
+extern "C" int rx_device_name(int device, char* buf, size_t buflen) {
+  if (!buf || buflen == 0) return RX_EINVAL;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return RX_OK;
+}
+
+template <typename T>
+static int upload_vec(const std::vector<T>& v, T** d) {
+  const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+  HIPCHK(hipMalloc((void**)d, bytes));
+  if (!v.empty()) HIPCHK(hipMemcpy(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return RX_OK;
+}
+
+// HBM copy of the automaton on `device` (current device must already be `device`).
+static int get_dev_tables(const rx_nfa* cnfa, int device, DevTables* out) {
+  rx_nfa* nfa = const_cast<rx_nfa*>(cnfa);
+  std::lock_guard<std::mutex> lk(nfa->mu);
+  auto it = nfa->dev.find(device);
+  if (it != nfa->dev.end()) { *out = it->second; return RX_OK; }
+  DevTables t;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  t.cu_count = prop.multiProcessorCount;
+  t.lds_per_cu = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor
+                                                       : prop.sharedMemPerBlock;
+  int rc;
+  if ((rc = upload_vec(nfa->h.words, &t.words))) return rc;  // the .coe words, unchanged
+  if ((rc = upload_vec(nfa->h.symidx, &t.symidx))) return rc;
+  if ((rc = upload_vec(nfa->h.ovf, &t.ovf))) return rc;
+  if ((rc = upload_vec(nfa->h.accept_bits, &t.accept_bits))) return rc;
+  nfa->dev[device] = t;
+  *out = t;
+  return RX_OK;
+}
+
+// ---- plan -----------------------------------------------------------------------------------------
+struct rx_plan {
+  const rx_nfa* nfa = nullptr;
+  rx_opts opts{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  DevTables tab;
+  size_t max_streams = 0, max_len = 0, events_cap = 0;
+  bool want_mc = false, want_am = false, want_final = false;
+  // device buffers
+  uint8_t* d_in_own = nullptr;
+  size_t d_in_own_bytes = 0;
+  const uint8_t* d_in = nullptr;
+  rx_event* d_events = nullptr;
+  unsigned long long* d_counters = nullptr;
+  uint32_t* d_mc = nullptr;
+  unsigned long long* d_mct = nullptr;
+  uint32_t* d_am = nullptr;
+  uint32_t* d_final = nullptr;
+  uint32_t* d_init = nullptr;
+  bool have_init = false;
+  size_t am_stride = 0;
+  // current batch
+  size_t n_streams = 0, stream_len = 0, stride = 0;
+  bool have_input = false, launched = false;
+  RxParams params{};
+  RxLaunchCfg cfg{};
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double last_ms = 0;
+};
+
+static uint64_t passes_for(size_t n, uint32_t mode) {
+  if (mode == RX_MODE_TB_COMPAT) return n >= 1 ? n - 1 : 0;  // testbench_BLK_Mem.sv:71: $finish at m == N
+  return (uint64_t)n + 1;
+}
+
+static int bind_device(int device, int* resolved) {
+  if (device < 0) {
+    HIPCHK(hipGetDevice(resolved));
+  } else {
+    HIPCHK(hipSetDevice(device));
+    *resolved = device;
+  }
+  return RX_OK;
+}
+
+extern "C" int rx_plan_create(const rx_nfa* nfa, const rx_opts* opts, size_t max_streams, size_t max_stream_len,
+                              size_t events_cap, uint32_t want_match_count, uint32_t want_anymatch,
+                              uint32_t want_final, rx_plan** out) {
+  if (!nfa || !out || max_streams == 0) return RX_EINVAL;
+  if (max_streams > 0xFFFFFFFFull || max_stream_len > 0xFFFFFFF0ull || events_cap > 0xFFFFFFFFull)
+    return RX_ECAPACITY;
+  rx_opts o{};
+  if (opts) o = *opts; else o.device = -1;
+  if (o.mode > RX_MODE_TB_COMPAT) return RX_EINVAL;
+  int ndev = 0;
+  {
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDeviceCount");
+    if (ndev <= 0) return RX_ENODEVICE;
+  }
+  rx_plan* p = new (std::nothrow) rx_plan();
+  if (!p) return RX_ENOMEM;
+  p->nfa = nfa;
+  p->opts = o;
+  p->stream = (hipStream_t)o.stream;
+  p->max_streams = max_streams;
+  p->max_len = max_stream_len;
+  p->events_cap = events_cap;
+  p->want_mc = want_match_count != 0;
+  p->want_am = want_anymatch != 0;
+  p->want_final = want_final != 0;
+  int rc = bind_device(o.device, &p->device);
+  if (rc) { delete p; return rc; }
+  rc = get_dev_tables(nfa, p->device, &p->tab);
+  if (rc) { delete p; return rc; }
+  const uint32_t size = nfa->h.size;
+  const size_t nw64x2 = 2 * (((size_t)size + 63) / 64);
+  auto fail = [&](int code) { rx_plan_free(p); return code; };
+#define PLCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(hip_fail(e_, #call)); } while (0)
+  PLCHK(hipMalloc((void**)&p->d_counters, 4 * sizeof(unsigned long long)));
+  PLCHK(hipMalloc((void**)&p->d_events, std::max<size_t>(events_cap, 1) * sizeof(rx_event)));
+  PLCHK(hipMalloc((void**)&p->d_mct, (size_t)size * sizeof(unsigned long long)));
+  if (p->want_mc) PLCHK(hipMalloc((void**)&p->d_mc, max_streams * size * sizeof(uint32_t)));
+  p->am_stride = (size_t)((passes_for(max_stream_len, RX_MODE_FULL) + 31) / 32);
+  if (p->want_am) PLCHK(hipMalloc((void**)&p->d_am, max_streams * p->am_stride * sizeof(uint32_t)));
+  if (p->want_final) PLCHK(hipMalloc((void**)&p->d_final, max_streams * nw64x2 * sizeof(uint32_t)));
+  PLCHK(hipEventCreate(&p->ev0));
+  PLCHK(hipEventCreate(&p->ev1));
+#undef PLCHK
+  *out = p;
+  return RX_OK;
+}
+
+extern "C" void rx_plan_free(rx_plan* p) {
+  if (!p) return;
+  int prev = -1;
+  bool have_prev = hipGetDevice(&prev) == hipSuccess;
+  (void)hipSetDevice(p->device);
+  (void)hipFree(p->d_in_own);
+  (void)hipFree(p->d_events);
+  (void)hipFree(p->d_counters);
+  (void)hipFree(p->d_mc);
+  (void)hipFree(p->d_mct);
+  (void)hipFree(p->d_am);
+  (void)hipFree(p->d_final);
+  (void)hipFree(p->d_init);
+  if (p->ev0) (void)hipEventDestroy(p->ev0);
+  if (p->ev1) (void)hipEventDestroy(p->ev1);
+  if (have_prev) (void)hipSetDevice(prev);
+  delete p;
+}
+
+static int set_batch(rx_plan* p, size_t n_streams, size_t stream_len, size_t stride) {
+  if (n_streams == 0 || n_streams > p->max_streams || stream_len > p->max_len || stride < stream_len)
+    return RX_EINVAL;
+  p->n_streams = n_streams;
+  p->stream_len = stream_len;
+  p->stride = stride;
+  p->have_input = true;
+  p->launched = false;
+  return RX_OK;
+}
+
+extern "C" int rx_plan_upload(rx_plan* p, const uint8_t* bytes, size_t n_streams, size_t stream_len,
+                              size_t stride) {
+  if (!p || (!bytes && stream_len)) return RX_EINVAL;
+  int dev;
+  int rc = bind_device(p->device, &dev);
+  if (rc) return rc;
+  rc = set_batch(p, n_streams, stream_len, stride);
+  if (rc) return rc;
+  // rows are packed to a 4-byte-aligned pitch in HBM so every lane can take a whole dword
+  const size_t pitch = (stream_len + 3) & ~(size_t)3;
+  const size_t need = std::max<size_t>(n_streams * pitch, 4);
+  if (need > p->d_in_own_bytes) {
+    (void)hipFree(p->d_in_own);
+    p->d_in_own = nullptr;
+    p->d_in_own_bytes = 0;
+    HIPCHK(hipMalloc((void**)&p->d_in_own, need));
+    p->d_in_own_bytes = need;
+  }
+  if (stream_len)
+    HIPCHK(hipMemcpy2DAsync(p->d_in_own, pitch, bytes, stride, stream_len, n_streams, hipMemcpyHostToDevice,
+                            p->stream));
+  p->d_in = p->d_in_own;
+  p->stride = pitch;
+  return RX_OK;
+}
+
+extern "C" int rx_plan_set_device_input(rx_plan* p, const void* device_bytes, size_t n_streams,
+                                        size_t stream_len, size_t stride) {
+  if (!p || (!device_bytes && stream_len)) return RX_EINVAL;
+  int rc = set_batch(p, n_streams, stream_len, stride);
+  if (rc) return rc;
+  p->d_in = (const uint8_t*)device_bytes;
+  return RX_OK;
+}
+
+extern "C" int rx_plan_set_init_active(rx_plan* p, const uint64_t* init_active) {
+  if (!p) return RX_EINVAL;
+  if (!init_active) { p->have_init = false; return RX_OK; }
+  if (!p->have_input) return RX_ESTATE;
+  int dev;
+  int rc = bind_device(p->device, &dev);
+  if (rc) return rc;
+  const size_t nw64 = ((size_t)p->nfa->h.size + 63) / 64;
+  if (!p->d_init) HIPCHK(hipMalloc((void**)&p->d_init, p->max_streams * nw64 * sizeof(uint64_t)));
+  HIPCHK(hipMemcpyAsync(p->d_init, init_active, p->n_streams * nw64 * sizeof(uint64_t), hipMemcpyHostToDevice,
+                        p->stream));
+  p->have_init = true;
+  return RX_OK;
+}
+
+extern "C" int rx_plan_launch(rx_plan* p) {
+  if (!p) return RX_EINVAL;
+  if (!p->have_input) return RX_ESTATE;
+  int dev;
+  int rc = bind_device(p->device, &dev);
+  if (rc) return rc;
+  const RxHostNfa& h = p->nfa->h;
+  RxParams& a = p->params;
+  a = RxParams{};
+  a.words = p->tab.words;
+  a.symidx = p->tab.symidx;
+  a.ovf = p->tab.ovf;
+  a.accept_bits = p->tab.accept_bits;
+  a.size = h.size;
+  a.bytes = p->d_in;
+  a.stride = p->stride;
+  a.n_streams = (uint32_t)p->n_streams;
+  a.stream_len = (uint32_t)p->stream_len;
+  a.n_passes = (uint32_t)passes_for(p->stream_len, p->opts.mode);
+  a.n_consume = p->opts.mode == RX_MODE_TB_COMPAT ? a.n_passes : (uint32_t)p->stream_len;
+  a.k_base = (uint32_t)p->opts.k_base;
+  a.state0_entry = (h.accept_bits[0] & 1u) ? RXE_ACCEPT : 0u;
+  a.nw64x2 = 2u * ((h.size + 63u) / 64u);
+  a.init_active = p->have_init ? p->d_init : nullptr;
+  a.events = p->events_cap ? p->d_events : nullptr;
+  a.events_cap = (uint32_t)p->events_cap;
+  a.counters = p->d_counters;
+  a.match_count = p->want_mc ? p->d_mc : nullptr;
+  a.match_count_total = p->d_mct;
+  a.anymatch = p->want_am ? p->d_am : nullptr;
+  a.anymatch_stride = (uint32_t)p->am_stride;
+  a.final_active = p->want_final ? p->d_final : nullptr;
+  rc = rx_pick_launch(p->opts.kernel, h.size, a.n_streams, p->tab.cu_count, p->tab.lds_per_cu, &a, &p->cfg);
+  if (rc) return rc;
+  p->cfg.stats = p->opts.collect_stats != 0;
+
+  HIPCHK(hipMemsetAsync(p->d_counters, 0, 4 * sizeof(unsigned long long), p->stream));
+  HIPCHK(hipMemsetAsync(p->d_mct, 0, (size_t)h.size * sizeof(unsigned long long), p->stream));
+  if (p->want_mc) HIPCHK(hipMemsetAsync(p->d_mc, 0, p->n_streams * h.size * sizeof(uint32_t), p->stream));
+  HIPCHK(hipEventRecord(p->ev0, p->stream));
+  hipError_t e = (hipError_t)rx_launch(a, p->cfg, p->stream);
+  if (e != hipSuccess) return hip_fail(e, "kernel launch");
+  HIPCHK(hipEventRecord(p->ev1, p->stream));
+  p->launched = true;
+  return RX_OK;
+}
+
+extern "C" int rx_plan_sync(rx_plan* p, double* kernel_ms) {
+  if (!p) return RX_EINVAL;
+  if (!p->launched) return RX_ESTATE;
+  HIPCHK(hipEventSynchronize(p->ev1));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+  p->last_ms = ms;
+  if (kernel_ms) *kernel_ms = ms;
+  return RX_OK;
+}
+
+static bool ev_less(const rx_event& a, const rx_event& b) {
+  if (a.stream != b.stream) return a.stream < b.stream;
+  if (a.k != b.k) return a.k < b.k;
+  return a.state < b.state;
+}
+
+extern "C" int rx_plan_download(rx_plan* p, rx_result* res) {
+  if (!p || !res) return RX_EINVAL;
+  if (!p->launched) return RX_ESTATE;
+  int dev;
+  int rc = bind_device(p->device, &dev);
+  if (rc) return rc;
+  rc = rx_plan_sync(p, nullptr);
+  if (rc) return rc;
+  const RxHostNfa& h = p->nfa->h;
+  unsigned long long cnt[4] = {0, 0, 0, 0};
+  HIPCHK(hipMemcpy(cnt, p->d_counters, sizeof(cnt), hipMemcpyDeviceToHost));
+  rx_stats& st = res->stats;
+  st = rx_stats{};
+  st.n_passes = p->params.n_passes;
+  st.n_events = cnt[0];
+  st.kernel_ms = p->last_ms;
+  st.kernel_used = p->cfg.kernel;
+  st.n_launches = 1;
+  if (p->cfg.stats) {
+    st.sum_active = cnt[1];
+    st.sum_edges = cnt[2];
+    // 1 B per consumed byte + 8 B per active state + 4 B per edge of its row
+    // + 1 bit per pass (per stream, rounded up to bytes) + 12 B per accept event
+    st.alg_bytes = (uint64_t)p->params.n_consume * p->n_streams + 8 * st.sum_active + 4 * st.sum_edges +
+                   (uint64_t)p->n_streams * ((st.n_passes + 7) / 8) + 12 * st.n_events;
+  }
+  const size_t captured = (size_t)std::min<unsigned long long>(cnt[0], p->events_cap);
+  res->events_overflow = cnt[0] > p->events_cap ? 1u : 0u;
+  res->n_events = 0;
+  if (res->events && res->events_cap && captured) {
+    std::vector<rx_event> tmp(captured);
+    HIPCHK(hipMemcpy(tmp.data(), p->d_events, captured * sizeof(rx_event), hipMemcpyDeviceToHost));
+    std::sort(tmp.begin(), tmp.end(), ev_less);  // device order is arrival order; canonical = (stream,k,state)
+    const size_t n = std::min(captured, res->events_cap);
+    memcpy(res->events, tmp.data(), n * sizeof(rx_event));
+    res->n_events = n;
+    if (captured > res->events_cap) res->events_overflow = 1u;
+  } else if (cnt[0] && (!res->events || !res->events_cap)) {
+    res->events_overflow = res->events ? 1u : 0u;
+  }
+  if (res->match_count) {
+    if (!p->want_mc) return RX_ESTATE;
+    HIPCHK(hipMemcpy(res->match_count, p->d_mc, p->n_streams * h.size * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  }
+  if (res->match_count_total)
+    HIPCHK(hipMemcpy(res->match_count_total, p->d_mct, (size_t)h.size * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  if (res->anymatch) {
+    if (!p->want_am) return RX_ESTATE;
+    const size_t need = (size_t)((st.n_passes + 31) / 32);
+    if (res->anymatch_stride < need) return RX_EINVAL;
+    if (need)
+      HIPCHK(hipMemcpy2D(res->anymatch, res->anymatch_stride * 4, p->d_am, p->am_stride * 4, need * 4, p->n_streams,
+                         hipMemcpyDeviceToHost));
+  }
+  if (res->final_active) {
+    if (!p->want_final) return RX_ESTATE;
+    HIPCHK(hipMemcpy(res->final_active, p->d_final, p->n_streams * p->params.nw64x2 * sizeof(uint32_t),
+                     hipMemcpyDeviceToHost));
+  }
+  return RX_OK;
+}
+
+// ---- one-shot -------------------------------------------------------------------------------------
+extern "C" int rx_match(const rx_nfa* nfa, const uint8_t* bytes, size_t n_streams, size_t stream_len, size_t stride,
+                        const uint64_t* init_active, const rx_opts* opts, rx_result* res) {
+  if (!nfa || !res || (!bytes && stream_len) || n_streams == 0 || stride < stream_len) return RX_EINVAL;
+  rx_plan* p = nullptr;
+  int rc = rx_plan_create(nfa, opts, n_streams, stream_len, res->events ? res->events_cap : 0,
+                          res->match_count != nullptr, res->anymatch != nullptr, res->final_active != nullptr, &p);
+  if (rc) return rc;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  auto done = [&](int code) {
+    if (t0) (void)hipEventDestroy(t0);
+    if (t1) (void)hipEventDestroy(t1);
+    rx_plan_free(p);
+    return code;
+  };
+  if (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess) return done(RX_EHIP);
+  (void)hipEventRecord(t0, p->stream);
+  if ((rc = rx_plan_upload(p, bytes, n_streams, stream_len, stride))) return done(rc);
+  if (init_active && (rc = rx_plan_set_init_active(p, init_active))) return done(rc);
+  (void)hipEventRecord(t1, p->stream);
+  if ((rc = rx_plan_launch(p))) return done(rc);
+  if ((rc = rx_plan_sync(p, nullptr))) return done(rc);
+  const auto w0 = std::chrono::steady_clock::now();
+  if ((rc = rx_plan_download(p, res))) return done(rc);
+  const auto w1 = std::chrono::steady_clock::now();
+  float h2d = 0;
+  (void)hipEventElapsedTime(&h2d, t0, t1);
+  res->stats.h2d_ms = h2d;
+  res->stats.d2h_ms = std::chrono::duration<double, std::milli>(w1 - w0).count();
+  return done(RX_OK);
+}
+
+// ---- multi-GPU: contiguous stream blocks, one host thread per device, no collective --------------
+extern "C" int rx_match_sharded(const rx_nfa* nfa, const uint8_t* bytes, size_t n_streams, size_t stream_len,
+                                size_t stride, const int* devices, int n_devices, const rx_opts* opts,
+                                rx_result* res) {
+  if (!nfa || !res || n_devices <= 0 || n_streams == 0 || stride < stream_len) return RX_EINVAL;
+  const int nd = (int)std::min<size_t>((size_t)n_devices, n_streams);
+  const uint32_t size = nfa->h.size;
+  const size_t nw64 = ((size_t)size + 63) / 64;
+  struct Shard {
+    size_t s0 = 0, n = 0;
+    rx_result r{};
+    std::vector<rx_event> ev;
+    std::vector<uint64_t> mct;
+    int rc = RX_OK;
+    std::string err;
+  };
+  std::vector<Shard> sh((size_t)nd);
+  const size_t per = n_streams / (size_t)nd, rem = n_streams % (size_t)nd;
+  size_t s = 0;
+  for (int d = 0; d < nd; d++) {  // remainder to the low ranks
+    sh[d].s0 = s;
+    sh[d].n = per + ((size_t)d < rem ? 1 : 0);
+    s += sh[d].n;
+  }
+  std::vector<std::thread> th;
+  for (int d = 0; d < nd; d++) {
+    th.emplace_back([&, d]() {
+      Shard& x = sh[d];
+      rx_opts o{};
+      if (opts) o = *opts;
+      o.device = devices ? devices[d] : d;
+      o.stream = nullptr;  // a stream handle belongs to one device
+      x.r = rx_result{};
+      if (res->events && res->events_cap) {
+        x.ev.resize(res->events_cap);
+        x.r.events = x.ev.data();
+        x.r.events_cap = res->events_cap;
+      }
+      if (res->match_count) x.r.match_count = res->match_count + x.s0 * size;
+      if (res->match_count_total) { x.mct.assign(size, 0); x.r.match_count_total = x.mct.data(); }
+      if (res->anymatch) { x.r.anymatch = res->anymatch + x.s0 * res->anymatch_stride; x.r.anymatch_stride = res->anymatch_stride; }
+      if (res->final_active) x.r.final_active = res->final_active + x.s0 * nw64;
+      x.rc = rx_match(nfa, bytes + x.s0 * stride, x.n, stream_len, stride, nullptr, &o, &x.r);
+      if (x.rc) x.err = rx_last_hip_error();
+    });
+  }
+  for (auto& t : th) t.join();
+  res->stats = rx_stats{};
+  res->n_events = 0;
+  res->events_overflow = 0;
+  if (res->match_count_total) memset(res->match_count_total, 0, (size_t)size * sizeof(uint64_t));
+  for (int d = 0; d < nd; d++) {
+    Shard& x = sh[d];
+    if (x.rc) { g_last_hip = x.err; return x.rc; }
+    for (size_t e = 0; e < x.r.n_events; e++) {  // shards are in stream order => output stays sorted
+      if (res->n_events < res->events_cap) {
+        rx_event ev = x.r.events[e];
+        ev.stream += (uint32_t)x.s0;
+        res->events[res->n_events++] = ev;
+      } else {
+        res->events_overflow = 1;
+      }
+    }
+    if (x.r.events_overflow) res->events_overflow = 1;
+    if (res->match_count_total)
+      for (uint32_t i = 0; i < size; i++) res->match_count_total[i] += x.mct[i];
+    res->stats.n_passes = x.r.stats.n_passes;
+    res->stats.n_events += x.r.stats.n_events;
+    res->stats.sum_active += x.r.stats.sum_active;
+    res->stats.sum_edges += x.r.stats.sum_edges;
+    res->stats.alg_bytes += x.r.stats.alg_bytes;
+    res->stats.kernel_ms = std::max(res->stats.kernel_ms, x.r.stats.kernel_ms);  // slowest device
+    res->stats.h2d_ms = std::max(res->stats.h2d_ms, x.r.stats.h2d_ms);
+    res->stats.d2h_ms = std::max(res->stats.d2h_ms, x.r.stats.d2h_ms);
+    res->stats.kernel_used = x.r.stats.kernel_used;
+    res->stats.n_launches += x.r.stats.n_launches;
+  }
+  return RX_OK;
+}

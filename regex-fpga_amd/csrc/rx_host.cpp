@@ -1,0 +1,184 @@
+// rx_host.cpp — host-side loaders for the reference's two file formats and the load-time
+// derivation of the per-(state,symbol) slice index.  Plain C++17, no HIP, no oracle code.
+//
+//   .coe  : Block_Mem/CSR_BlockMem*.coe — Xilinx COE, radix 16, one 128-bit token per BRAM line.
+//           Token -> four u32, leftmost 8 hex digits = word 0 (Design/FPGA.v:881-884:
+//           cache[0] = rd_bus[127:96]).  The word array is kept UNCHANGED; it is what goes to HBM.
+//   .mem  : Simulation/input_trace_*.mem — $readmemh text read by testbench_BLK_Mem.sv:34-35.
+//   table : W[0..size] = row_ptr, W[size+1+row_ptr[i]+j] = (symbol<<24 | target)
+//           (Design/FPGA.v:773,793 offset = size+1; :888-898 field split).
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+#include "rx_internal.hpp"
+
+static inline int hexv(unsigned char c) {
+  if (c >= '0' && c <= '9') return c - '0';
+  c |= 0x20;
+  if (c >= 'a' && c <= 'f') return c - 'a' + 10;
+  return -1;
+}
+static inline bool is_sep(unsigned char c) {
+  return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == ',' || c == ';' || c == '\f' || c == '\v';
+}
+
+int rxh_read_file(const char* path, std::string* out) {
+  if (!path) return RX_EINVAL;
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return RX_EIO;
+  std::ostringstream ss;
+  ss << f.rdbuf();
+  if (f.bad()) return RX_EIO;
+  *out = ss.str();
+  return RX_OK;
+}
+
+int rxh_parse_coe_text(const char* text, size_t len, std::vector<uint32_t>* words) {
+  const std::string s(text, len);
+  // header: memory_initialization_radix=16; memory_initialization_vector=
+  size_t r = s.find("memory_initialization_radix");
+  if (r == std::string::npos) return RX_EFORMAT;
+  size_t eq = s.find('=', r);
+  if (eq == std::string::npos) return RX_EFORMAT;
+  size_t q = eq + 1;
+  while (q < s.size() && (s[q] == ' ' || s[q] == '\t')) q++;
+  if (s.compare(q, 2, "16") != 0) return RX_EFORMAT;  // only radix 16 is produced by the reference
+  size_t v = s.find("memory_initialization_vector");
+  if (v == std::string::npos) return RX_EFORMAT;
+  eq = s.find('=', v);
+  if (eq == std::string::npos) return RX_EFORMAT;
+  words->clear();
+  words->reserve((s.size() - eq) / 33 * 4 + 8);
+  size_t i = eq + 1;
+  while (i < s.size()) {
+    while (i < s.size() && is_sep((unsigned char)s[i])) i++;
+    if (i >= s.size()) break;
+    size_t j = i;
+    while (j < s.size() && hexv((unsigned char)s[j]) >= 0) j++;
+    if (j - i != 32) return RX_EFORMAT;  // every token is one 128-bit line
+    if (j < s.size() && !is_sep((unsigned char)s[j])) return RX_EFORMAT;
+    for (int lane = 0; lane < 4; lane++) {
+      uint32_t w = 0;
+      for (int d = 0; d < 8; d++) w = (w << 4) | (uint32_t)hexv((unsigned char)s[i + (size_t)lane * 8 + d]);
+      words->push_back(w);
+    }
+    i = j;
+  }
+  return words->empty() ? RX_EFORMAT : RX_OK;
+}
+
+int rxh_parse_mem_text(const char* text, size_t len, std::vector<uint8_t>* bytes) {
+  bytes->clear();
+  bytes->reserve(len / 3 + 1);
+  size_t i = 0;
+  while (i < len) {
+    while (i < len && (text[i] == ' ' || text[i] == '\t' || text[i] == '\n' || text[i] == '\r')) i++;
+    if (i >= len) break;
+    unsigned v = 0;
+    size_t nd = 0;
+    while (i < len && hexv((unsigned char)text[i]) >= 0) { v = v * 16 + (unsigned)hexv((unsigned char)text[i]); i++; nd++; }
+    if (nd == 0 || nd > 2) return RX_EFORMAT;  // 8-bit memory: at most two hex digits per entry
+    if (i < len && !(text[i] == ' ' || text[i] == '\t' || text[i] == '\n' || text[i] == '\r')) return RX_EFORMAT;
+    bytes->push_back((uint8_t)v);
+  }
+  return RX_OK;
+}
+
+// size is not stored in the file (the reference passes it as a parameter,
+// testbench_BLK_Mem.sv:20).  Unique s with: W[0]=0, W[0..s] non-decreasing, W[s]+s+1 words used,
+// 0-3 zero pad words, every target < s.
+int rxh_infer_size(const uint32_t* W, size_t nwords, uint32_t* size) {
+  if (!W || nwords < 2 || W[0] != 0) return RX_ENFA;
+  uint32_t hit = 0;
+  int nhit = 0;
+  for (size_t s = 1; s < nwords && s <= 0xFFFFFFu; s++) {
+    if (W[s] < W[s - 1]) break;
+    const uint64_t used = (uint64_t)W[s] + s + 1;
+    if (used > nwords || nwords - used > 3) continue;
+    if (rxh_validate(W, nwords, (uint32_t)s) == RX_OK) { hit = (uint32_t)s; nhit++; }
+  }
+  if (nhit != 1) return RX_ENFA;
+  *size = hit;
+  return RX_OK;
+}
+
+int rxh_validate(const uint32_t* W, size_t nwords, uint32_t size) {
+  if (!W || size == 0 || size > 0xFFFFFFu || (size_t)size + 1 > nwords) return RX_ENFA;
+  if (W[0] != 0) return RX_ENFA;
+  for (uint32_t i = 0; i < size; i++)
+    if (W[i + 1] < W[i]) return RX_ENFA;
+  const uint64_t nnz = W[size];
+  const uint64_t used = nnz + size + 1;
+  if (used > nwords || nwords - used > 3) return RX_ENFA;
+  for (uint64_t j = used; j < nwords; j++)
+    if (W[j] != 0) return RX_ENFA;
+  const uint32_t* col = W + size + 1;
+  for (uint64_t e = 0; e < nnz; e++)
+    if ((col[e] & 0xFFFFFFu) >= size) return RX_ENFA;  // next[] is size bits wide (FPGA.v:54)
+  return RX_OK;
+}
+
+int rxh_build(const uint32_t* W, size_t nwords, uint32_t size_or_0, RxHostNfa* out) {
+  uint32_t size = size_or_0;
+  if (size == 0) {
+    int rc = rxh_infer_size(W, nwords, &size);
+    if (rc) return rc;
+  } else {
+    int rc = rxh_validate(W, nwords, size);
+    if (rc) return rc;
+  }
+  out->words.assign(W, W + nwords);
+  out->size = size;
+  out->nnz = W[size];
+  const uint32_t* rp = out->row_ptr();
+  const uint32_t* col = out->col();
+  out->n_accept = 0;
+  out->max_degree = 0;
+  out->accept_bits.assign(((size_t)size + 31) / 32, 0u);
+  for (uint32_t i = 0; i < size; i++) {
+    const uint32_t deg = rp[i + 1] - rp[i];
+    out->max_degree = std::max(out->max_degree, deg);
+    if (deg == 0) {  // accept <=> empty row (FPGA.v:210)
+      out->n_accept++;
+      out->accept_bits[i >> 5] |= 1u << (i & 31);
+    }
+  }
+  auto is_acc = [&](uint32_t t) { return (out->accept_bits[t >> 5] >> (t & 31)) & 1u; };
+
+  // ---- slice index: for every (state, symbol) the SET of targets its row yields -------------
+  out->symidx.assign((size_t)size * 256, 0u);
+  out->ovf.assign(1, 0u);
+  std::vector<uint32_t> bucket[256];
+  for (uint32_t i = 0; i < size; i++) {
+    const uint32_t base = rp[i], deg = rp[i + 1] - base;
+    if (deg == 0) continue;
+    for (auto& b : bucket) b.clear();
+    for (uint32_t j = 0; j < deg; j++) {
+      const uint32_t w = col[base + j];
+      bucket[w >> 24].push_back(w & 0xFFFFFFu);
+    }
+    for (int c = 0; c < 256; c++) {
+      auto& b = bucket[c];
+      if (b.empty()) continue;
+      std::sort(b.begin(), b.end());
+      b.erase(std::unique(b.begin(), b.end()), b.end());  // next[t] <= 1 is idempotent
+      uint32_t ent = 0;
+      auto self = std::find(b.begin(), b.end(), i);
+      if (self != b.end()) { ent |= RXE_SELF; b.erase(self); }
+      if (b.size() == 1) {
+        ent |= RXE_INLINE | b[0] | (is_acc(b[0]) ? RXE_ACCEPT : 0u);
+      } else if (b.size() >= 2) {
+        const size_t off = out->ovf.size();
+        if (off + b.size() + 1 > RXE_TGT_MASK) return RX_ECAPACITY;
+        out->ovf.push_back((uint32_t)b.size());
+        for (uint32_t t : b) out->ovf.push_back(t | (is_acc(t) ? RXE_ACCEPT : 0u));
+        ent |= RXE_OVF | (uint32_t)off;
+      }
+      out->symidx[(size_t)i * 256 + c] = ent;
+    }
+  }
+  return RX_OK;
+}

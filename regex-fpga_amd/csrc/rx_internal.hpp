@@ -1,0 +1,93 @@
+// rx_internal.hpp — shared between the host side (rx_host.cpp, rx_api.hip) and the gfx950 kernels
+// (rx_kernels.hip).  Not part of the C-ABI; the boundary is include/rxmatch.h.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/rxmatch.h"
+
+// ---- slice-index entry encoding (derived at load time from the unchanged CSR table) ---------
+// One u32 per (state, symbol): what row(state) — Design/FPGA.v:227-714 — yields for that byte.
+//   0                       no edge of this state carries the symbol
+//   RXE_INLINE | tgt        exactly one non-self target, held inline (bits 23:0)
+//   RXE_ACCEPT              the inline target is an accept state (empty row, FPGA.v:210-226)
+//   RXE_SELF                the state has an edge to ITSELF on this symbol (e.g. the `.*` state)
+//   RXE_OVF | off           >= 2 non-self targets: ovf[off] = count, ovf[off+1..] = targets
+//                           (each target word may carry RXE_ACCEPT)
+static constexpr uint32_t RXE_INLINE = 0x80000000u;
+static constexpr uint32_t RXE_ACCEPT = 0x40000000u;
+static constexpr uint32_t RXE_SELF = 0x20000000u;
+static constexpr uint32_t RXE_OVF = 0x10000000u;
+static constexpr uint32_t RXE_TGT_MASK = 0x00FFFFFFu;
+
+// Active-list entry (LDS): state id in bits 23:0, RXE_ACCEPT if the state is an accept state.
+
+static constexpr uint32_t RX_LIST_CAP = 128;  // sparse active-list capacity per stream (entries)
+static constexpr uint32_t RX_SMALL_DEG = 8;   // CSR kernel: rows up to this length are scanned per lane
+
+// Kernel argument block (passed by value).
+struct RxParams {
+  // automaton in HBM — `words` is the .coe content unchanged: row_ptr = words, col = words+size+1
+  const uint32_t* words;
+  const uint32_t* symidx;       // [size][256] slice index (null for the CSR kernel)
+  const uint32_t* ovf;          // overflow target lists of the slice index
+  const uint32_t* accept_bits;  // [nw32] bit i set iff deg(i) == 0
+  uint32_t size;
+  uint32_t nw32;                // ceil(size/32)
+  // input streams
+  const uint8_t* bytes;
+  uint64_t stride;
+  uint32_t n_streams;
+  uint32_t stream_len;
+  uint32_t n_passes;            // accept checks per stream
+  uint32_t n_consume;           // bytes consumed per stream (= n_passes in tb-compat, N in full mode)
+  uint32_t k_base;
+  uint32_t state0_entry;        // list entry for reset state 0 (accept flag folded in)
+  const uint32_t* init_active;  // optional [n_streams][2*nw64] start bitmasks (u64 rows viewed as u32)
+  uint32_t nw64x2;              // u32 words per init/final row = 2*ceil(size/64)
+  // outputs
+  rx_event* events;
+  uint32_t events_cap;
+  unsigned long long* counters; // [0] n_events  [1] sum_active  [2] sum_edges
+  uint32_t* match_count;        // [n_streams][size] or null
+  unsigned long long* match_count_total; // [size] or null
+  uint32_t* anymatch;           // [n_streams][anymatch_stride] or null
+  uint32_t anymatch_stride;
+  uint32_t* final_active;       // [n_streams][nw64x2] or null
+  // LDS carve
+  uint32_t lds_words_per_stream;
+};
+
+struct RxLaunchCfg {
+  uint32_t kernel;         // RX_KERNEL_* (resolved, never AUTO)
+  uint32_t block_threads;
+  uint32_t grid_blocks;
+  uint32_t lds_bytes;      // dynamic LDS per block
+  bool stats;
+};
+
+// rx_kernels.hip
+int rx_pick_launch(uint32_t kernel, uint32_t size, uint32_t n_streams, int cu_count, size_t lds_per_cu,
+                   RxParams* p, RxLaunchCfg* cfg);
+int rx_launch(const RxParams& p, const RxLaunchCfg& cfg, void* hip_stream);
+
+// ---- host-side automaton (rx_host.cpp; no HIP in here) ---------------------------------------
+struct RxHostNfa {
+  std::vector<uint32_t> words;  // exactly the .coe words incl. pad
+  uint32_t size = 0, nnz = 0, n_accept = 0, max_degree = 0;
+  // derived
+  std::vector<uint32_t> symidx;       // size*256
+  std::vector<uint32_t> ovf;          // ovf[0] unused so that offset 0 never occurs
+  std::vector<uint32_t> accept_bits;  // ceil(size/32)
+  const uint32_t* row_ptr() const { return words.data(); }
+  const uint32_t* col() const { return words.data() + size + 1; }
+};
+
+int rxh_parse_coe_text(const char* text, size_t len, std::vector<uint32_t>* words);
+int rxh_read_file(const char* path, std::string* out);
+int rxh_infer_size(const uint32_t* W, size_t nwords, uint32_t* size);
+int rxh_validate(const uint32_t* W, size_t nwords, uint32_t size);
+int rxh_build(const uint32_t* W, size_t nwords, uint32_t size_or_0, RxHostNfa* out);
+int rxh_parse_mem_text(const char* text, size_t len, std::vector<uint8_t>* bytes);

@@ -1,0 +1,338 @@
+"""ctypes binding of librxmatch.so — one Python call per C-ABI entry point (include/rxmatch.h).
+
+Mirrors the reference's only interface, the ports + protocol of `CSR_traversal` as driven by
+`Blk_Mem_tb` (Design/FPGA.v:23-43, Simulation/testbench_BLK_Mem.sv:49-87): load a .coe, load
+.mem traces, feed bytes, get accept pulses back.  No computation happens here; if the HIP library is
+missing this module raises instead of falling back to anything.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+MODE_FULL, MODE_TB_COMPAT = 0, 1
+KERNEL_AUTO, KERNEL_CSR_WAVE, KERNEL_SYM_WAVE, KERNEL_SYM_GROUP = 0, 1, 2, 3
+KERNEL_NAMES = {0: "auto", 1: "csr_wave", 2: "sym_wave", 3: "sym_group"}
+
+EVENT_DT = np.dtype([("stream", "<u4"), ("k", "<u4"), ("state", "<u4")])
+
+
+class RxError(RuntimeError):
+    def __init__(self, code, what):
+        self.code = code
+        L = lib()
+        msg = L.rx_strerror(code).decode()
+        hip = L.rx_last_hip_error().decode()
+        super().__init__(f"{what}: {msg} [{code}]" + (f" — {hip}" if hip and code in (-6, -7, -5) else ""))
+
+
+class _Opts(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("mode", C.c_uint32), ("kernel", C.c_uint32),
+                ("stream", C.c_void_p), ("k_base", C.c_uint64), ("collect_stats", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+class _Stats(C.Structure):
+    _fields_ = [("n_passes", C.c_uint64), ("n_events", C.c_uint64), ("sum_active", C.c_uint64),
+                ("sum_edges", C.c_uint64), ("alg_bytes", C.c_uint64), ("kernel_ms", C.c_double),
+                ("h2d_ms", C.c_double), ("d2h_ms", C.c_double), ("kernel_used", C.c_uint32),
+                ("n_launches", C.c_uint32)]
+
+
+class _Result(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("events_overflow", C.c_uint32), ("events", C.c_void_p),
+                ("events_cap", C.c_size_t), ("n_events", C.c_size_t), ("match_count", C.c_void_p),
+                ("match_count_total", C.c_void_p), ("anymatch", C.c_void_p), ("anymatch_stride", C.c_size_t),
+                ("final_active", C.c_void_p), ("stats", _Stats)]
+
+
+class _Info(C.Structure):
+    _fields_ = [("size", C.c_uint32), ("nnz", C.c_uint32), ("n_accept", C.c_uint32), ("n_words", C.c_uint32),
+                ("max_degree", C.c_uint32), ("n_bitmask_words64", C.c_uint32)]
+
+
+# every symbol include/rxmatch.h declares
+ABI_SYMBOLS = ["rx_strerror", "rx_last_hip_error", "rx_abi_version", "rx_nfa_load_coe", "rx_nfa_from_words",
+               "rx_nfa_get_info", "rx_nfa_words", "rx_nfa_free", "rx_trace_load_mem", "rx_free", "rx_match",
+               "rx_match_sharded", "rx_plan_create", "rx_plan_upload", "rx_plan_set_device_input",
+               "rx_plan_set_init_active", "rx_plan_launch", "rx_plan_sync", "rx_plan_download", "rx_plan_free",
+               "rx_device_count", "rx_device_name"]
+
+_lib = None
+
+
+def lib_path():
+    return os.path.join(_HERE, "librxmatch.so")
+
+
+def lib():
+    """Load librxmatch.so (built in-tree by __graft_entry__.build() / csrc/Makefile).  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise ImportError(f"{p} is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    L = C.CDLL(p)
+    vp, sz, u32, i32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int
+    L.rx_strerror.restype = C.c_char_p
+    L.rx_strerror.argtypes = [i32]
+    L.rx_last_hip_error.restype = C.c_char_p
+    L.rx_abi_version.restype = i32
+    L.rx_nfa_load_coe.argtypes = [C.c_char_p, u32, C.POINTER(vp)]
+    L.rx_nfa_from_words.argtypes = [vp, sz, u32, C.POINTER(vp)]
+    L.rx_nfa_get_info.argtypes = [vp, C.POINTER(_Info)]
+    L.rx_nfa_words.restype = C.POINTER(C.c_uint32)
+    L.rx_nfa_words.argtypes = [vp, C.POINTER(sz)]
+    L.rx_nfa_free.argtypes = [vp]
+    L.rx_nfa_free.restype = None
+    L.rx_trace_load_mem.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(sz)]
+    L.rx_free.argtypes = [vp]
+    L.rx_free.restype = None
+    L.rx_match.argtypes = [vp, vp, sz, sz, sz, vp, C.POINTER(_Opts), C.POINTER(_Result)]
+    L.rx_match_sharded.argtypes = [vp, vp, sz, sz, sz, C.POINTER(C.c_int), i32, C.POINTER(_Opts), C.POINTER(_Result)]
+    L.rx_plan_create.argtypes = [vp, C.POINTER(_Opts), sz, sz, sz, u32, u32, u32, C.POINTER(vp)]
+    L.rx_plan_upload.argtypes = [vp, vp, sz, sz, sz]
+    L.rx_plan_set_device_input.argtypes = [vp, vp, sz, sz, sz]
+    L.rx_plan_set_init_active.argtypes = [vp, vp]
+    L.rx_plan_launch.argtypes = [vp]
+    L.rx_plan_sync.argtypes = [vp, C.POINTER(C.c_double)]
+    L.rx_plan_download.argtypes = [vp, C.POINTER(_Result)]
+    L.rx_plan_free.argtypes = [vp]
+    L.rx_plan_free.restype = None
+    L.rx_device_count.argtypes = [C.POINTER(i32)]
+    L.rx_device_name.argtypes = [i32, C.c_char_p, sz]
+    _lib = L
+    return L
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise RxError(rc, what)
+
+
+def device_count():
+    n = C.c_int(0)
+    _chk(lib().rx_device_count(C.byref(n)), "rx_device_count")
+    return n.value
+
+
+def device_name(dev=0):
+    buf = C.create_string_buffer(256)
+    _chk(lib().rx_device_name(dev, buf, 256), "rx_device_name")
+    return buf.value.decode()
+
+
+def load_mem(path):
+    """$readmemh trace -> np.uint8 array (testbench_BLK_Mem.sv:34-35)."""
+    p, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+    _chk(lib().rx_trace_load_mem(os.fsencode(path), C.byref(p), C.byref(n)), f"rx_trace_load_mem({path})")
+    out = np.ctypeslib.as_array(p, shape=(max(n.value, 1),))[:n.value].copy()
+    lib().rx_free(p)
+    return out
+
+
+class Nfa:
+    """Immutable CSR automaton handle (rx_nfa).  `words` is the .coe content unchanged."""
+
+    def __init__(self, handle):
+        self._h = handle
+        info = _Info()
+        _chk(lib().rx_nfa_get_info(self._h, C.byref(info)), "rx_nfa_get_info")
+        self.size, self.nnz, self.n_accept = info.size, info.nnz, info.n_accept
+        self.n_words, self.max_degree, self.nw64 = info.n_words, info.max_degree, info.n_bitmask_words64
+
+    @classmethod
+    def load_coe(cls, path, size=0):
+        h = C.c_void_p()
+        _chk(lib().rx_nfa_load_coe(os.fsencode(path), size, C.byref(h)), f"rx_nfa_load_coe({path})")
+        return cls(h)
+
+    @classmethod
+    def from_words(cls, words, size=0):
+        w = np.ascontiguousarray(words, dtype=np.uint32)
+        h = C.c_void_p()
+        _chk(lib().rx_nfa_from_words(w.ctypes.data_as(C.c_void_p), w.size, size, C.byref(h)), "rx_nfa_from_words")
+        return cls(h)
+
+    @property
+    def words(self):
+        n = C.c_size_t()
+        p = lib().rx_nfa_words(self._h, C.byref(n))
+        return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+
+    def close(self):
+        if self._h:
+            lib().rx_nfa_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def n_passes(stream_len, mode):
+    if mode == MODE_TB_COMPAT:
+        return max(stream_len - 1, 0)
+    return stream_len + 1
+
+
+def _mk_opts(device, mode, kernel, stream, k_base, collect_stats):
+    o = _Opts()
+    o.struct_size = C.sizeof(_Opts)
+    o.device, o.mode, o.kernel = device, mode, kernel
+    o.stream = stream
+    o.k_base = k_base
+    o.collect_stats = 1 if collect_stats else 0
+    return o
+
+
+class _Out:
+    """Caller-allocated output arrays for one rx_result."""
+
+    def __init__(self, nfa, n_streams, stream_len, mode, events_cap, want_match_count, want_total, want_anymatch,
+                 want_final):
+        self.npass = n_passes(stream_len, mode)
+        self.ev = np.zeros(max(events_cap, 1), dtype=EVENT_DT) if events_cap else None
+        self.mc = np.zeros((n_streams, nfa.size), np.uint32) if want_match_count else None
+        self.tot = np.zeros(nfa.size, np.uint64) if want_total else None
+        self.am_stride = max((self.npass + 31) // 32, 1)
+        self.am = np.zeros((n_streams, self.am_stride), np.uint32) if want_anymatch else None
+        self.fin = np.zeros((n_streams, nfa.nw64), np.uint64) if want_final else None
+        r = _Result()
+        r.struct_size = C.sizeof(_Result)
+        if self.ev is not None:
+            r.events, r.events_cap = self.ev.ctypes.data, events_cap
+        if self.mc is not None:
+            r.match_count = self.mc.ctypes.data
+        if self.tot is not None:
+            r.match_count_total = self.tot.ctypes.data
+        if self.am is not None:
+            r.anymatch, r.anymatch_stride = self.am.ctypes.data, self.am_stride
+        if self.fin is not None:
+            r.final_active = self.fin.ctypes.data
+        self.r = r
+
+    def as_dict(self):
+        r, s = self.r, self.r.stats
+        return dict(events=self.ev[:r.n_events] if self.ev is not None else None, n_events=int(s.n_events),
+                    events_overflow=bool(r.events_overflow), match_count=self.mc, match_count_total=self.tot,
+                    anymatch=self.am, final_active=self.fin,
+                    stats=dict(n_passes=int(s.n_passes), n_events=int(s.n_events), sum_active=int(s.sum_active),
+                               sum_edges=int(s.sum_edges), alg_bytes=int(s.alg_bytes), kernel_ms=s.kernel_ms,
+                               h2d_ms=s.h2d_ms, d2h_ms=s.d2h_ms, kernel_used=int(s.kernel_used),
+                               n_launches=int(s.n_launches)))
+
+
+def _as_rows(data):
+    data = np.asarray(data, dtype=np.uint8)
+    if data.ndim == 1:
+        data = data[None, :]
+    if data.ndim != 2:
+        raise ValueError("data must be [n_streams, stream_len] uint8")
+    if data.shape[1] and data.strides[1] != 1:
+        data = np.ascontiguousarray(data)
+    stride = data.strides[0] if data.shape[0] > 1 else max(data.shape[1], 1)
+    if stride < data.shape[1]:
+        data = np.ascontiguousarray(data)
+        stride = data.shape[1]
+    return data, stride
+
+
+def match(nfa, data, mode=MODE_FULL, kernel=KERNEL_AUTO, device=-1, init_active=None, events_cap=1 << 20,
+          want_match_count=False, want_total=True, want_anymatch=True, want_final=True, collect_stats=False,
+          k_base=0):
+    """rx_match(): one-shot match of uint8 [n_streams, stream_len] host rows on one GPU."""
+    data, stride = _as_rows(data)
+    ns, sl = data.shape
+    out = _Out(nfa, ns, sl, mode, events_cap, want_match_count, want_total, want_anymatch, want_final)
+    o = _mk_opts(device, mode, kernel, None, k_base, collect_stats)
+    ia = None
+    if init_active is not None:
+        ia = np.ascontiguousarray(init_active, dtype=np.uint64)
+        if ia.shape != (ns, nfa.nw64):
+            raise ValueError("init_active must be [n_streams, ceil(size/64)] uint64")
+    _chk(lib().rx_match(nfa._h, data.ctypes.data, ns, sl, stride, ia.ctypes.data if ia is not None else None,
+                        C.byref(o), C.byref(out.r)), "rx_match")
+    return out.as_dict()
+
+
+def match_sharded(nfa, data, devices, mode=MODE_FULL, kernel=KERNEL_AUTO, events_cap=1 << 20,
+                  want_match_count=False, want_total=True, want_anymatch=True, want_final=True, collect_stats=False):
+    """rx_match_sharded(): contiguous stream blocks over several GPUs of this process, no collective."""
+    data, stride = _as_rows(data)
+    ns, sl = data.shape
+    out = _Out(nfa, ns, sl, mode, events_cap, want_match_count, want_total, want_anymatch, want_final)
+    o = _mk_opts(-1, mode, kernel, None, 0, collect_stats)
+    devs = (C.c_int * len(devices))(*devices)
+    _chk(lib().rx_match_sharded(nfa._h, data.ctypes.data, ns, sl, stride, devs, len(devices), C.byref(o),
+                                C.byref(out.r)), "rx_match_sharded")
+    return out.as_dict()
+
+
+class Plan:
+    """rx_plan: inputs stay resident in HBM across launches (serving / benchmarking)."""
+
+    def __init__(self, nfa, max_streams, max_stream_len, mode=MODE_FULL, kernel=KERNEL_AUTO, device=-1, stream=None,
+                 events_cap=1 << 20, want_match_count=False, want_anymatch=True, want_final=True, collect_stats=False,
+                 k_base=0):
+        self.nfa, self.mode = nfa, mode
+        self.events_cap = events_cap
+        self.want = (want_match_count, want_anymatch, want_final)
+        self._o = _mk_opts(device, mode, kernel, stream, k_base, collect_stats)
+        self._h = C.c_void_p()
+        _chk(lib().rx_plan_create(nfa._h, C.byref(self._o), max_streams, max_stream_len, events_cap,
+                                  int(want_match_count), int(want_anymatch), int(want_final), C.byref(self._h)),
+             "rx_plan_create")
+        self.n_streams = self.stream_len = 0
+        self._keep = None
+
+    def upload(self, data):
+        data, stride = _as_rows(data)
+        self.n_streams, self.stream_len = data.shape
+        _chk(lib().rx_plan_upload(self._h, data.ctypes.data, self.n_streams, self.stream_len, stride),
+             "rx_plan_upload")
+
+    def set_device_input(self, dptr, n_streams, stream_len, stride, keepalive=None):
+        """dptr: device address (e.g. torch_tensor.data_ptr()); keepalive pins the owner object."""
+        self.n_streams, self.stream_len = n_streams, stream_len
+        self._keep = keepalive
+        _chk(lib().rx_plan_set_device_input(self._h, dptr, n_streams, stream_len, stride),
+             "rx_plan_set_device_input")
+
+    def set_init_active(self, init_active):
+        if init_active is None:
+            _chk(lib().rx_plan_set_init_active(self._h, None), "rx_plan_set_init_active")
+            return
+        ia = np.ascontiguousarray(init_active, dtype=np.uint64)
+        _chk(lib().rx_plan_set_init_active(self._h, ia.ctypes.data), "rx_plan_set_init_active")
+
+    def launch(self):
+        _chk(lib().rx_plan_launch(self._h), "rx_plan_launch")
+
+    def sync(self):
+        ms = C.c_double()
+        _chk(lib().rx_plan_sync(self._h, C.byref(ms)), "rx_plan_sync")
+        return ms.value
+
+    def download(self, want_total=True):
+        wmc, wam, wfin = self.want
+        out = _Out(self.nfa, self.n_streams, self.stream_len, self.mode, self.events_cap, wmc, want_total, wam, wfin)
+        _chk(lib().rx_plan_download(self._h, C.byref(out.r)), "rx_plan_download")
+        return out.as_dict()
+
+    def close(self):
+        if self._h:
+            lib().rx_plan_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
