@@ -181,6 +181,10 @@ int rx_plan_set_init_active(rx_plan* plan, const uint64_t* init_active);
 int rx_plan_launch(rx_plan* plan);
 /* Wait for the last launch; kernel_ms (optional) = its hipEvent duration. */
 int rx_plan_sync(rx_plan* plan, double* kernel_ms);
+/* hipEvent durations of every launch since the previous call (or plan creation): their number,
+ * sum, minimum and maximum in ms.  Waits for the last launch.  Any pointer may be NULL. */
+int rx_plan_kernel_times(rx_plan* plan, uint32_t* n_launches, double* sum_ms, double* min_ms,
+                         double* max_ms);
 /* Copy the last launch's results to the caller's arrays (sorted events, counts, ...). */
 int rx_plan_download(rx_plan* plan, rx_result* res);
 void rx_plan_free(rx_plan* plan);

@@ -211,7 +211,9 @@ struct rx_plan {
   bool have_input = false, launched = false;
   RxParams params{};
   RxLaunchCfg cfg{};
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // one hipEvent pair per launch since the last rx_plan_kernel_times() call
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
+  size_t n_timed = 0;
   double last_ms = 0;
 };
 
@@ -271,8 +273,6 @@ extern "C" int rx_plan_create(const rx_nfa* nfa, const rx_opts* opts, size_t max
   p->am_stride = (size_t)((passes_for(max_stream_len, RX_MODE_FULL) + 31) / 32);
   if (p->want_am) PLCHK(hipMalloc((void**)&p->d_am, max_streams * p->am_stride * sizeof(uint32_t)));
   if (p->want_final) PLCHK(hipMalloc((void**)&p->d_final, max_streams * nw64x2 * sizeof(uint32_t)));
-  PLCHK(hipEventCreate(&p->ev0));
-  PLCHK(hipEventCreate(&p->ev1));
 #undef PLCHK
   *out = p;
   return RX_OK;
@@ -291,8 +291,7 @@ extern "C" void rx_plan_free(rx_plan* p) {
   (void)hipFree(p->d_am);
   (void)hipFree(p->d_final);
   (void)hipFree(p->d_init);
-  if (p->ev0) (void)hipEventDestroy(p->ev0);
-  if (p->ev1) (void)hipEventDestroy(p->ev1);
+  for (auto& e : p->evs) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (have_prev) (void)hipSetDevice(prev);
   delete p;
 }
@@ -397,20 +396,51 @@ extern "C" int rx_plan_launch(rx_plan* p) {
   HIPCHK(hipMemsetAsync(p->d_counters, 0, 4 * sizeof(unsigned long long), p->stream));
   HIPCHK(hipMemsetAsync(p->d_mct, 0, (size_t)h.size * sizeof(unsigned long long), p->stream));
   if (p->want_mc) HIPCHK(hipMemsetAsync(p->d_mc, 0, p->n_streams * h.size * sizeof(uint32_t), p->stream));
-  HIPCHK(hipEventRecord(p->ev0, p->stream));
+  if (p->n_timed >= 4096) p->n_timed = 0;  // nobody is reading the times: recycle the pool
+  if (p->n_timed == p->evs.size()) {
+    hipEvent_t a0 = nullptr, a1 = nullptr;
+    HIPCHK(hipEventCreate(&a0));
+    HIPCHK(hipEventCreate(&a1));
+    p->evs.emplace_back(a0, a1);
+  }
+  auto& ev = p->evs[p->n_timed];
+  HIPCHK(hipEventRecord(ev.first, p->stream));  // brackets the match kernel only, on its own stream
   hipError_t e = (hipError_t)rx_launch(a, p->cfg, p->stream);
   if (e != hipSuccess) return hip_fail(e, "kernel launch");
-  HIPCHK(hipEventRecord(p->ev1, p->stream));
+  HIPCHK(hipEventRecord(ev.second, p->stream));
+  p->n_timed++;
   p->launched = true;
+  return RX_OK;
+}
+
+extern "C" int rx_plan_kernel_times(rx_plan* p, uint32_t* n_launches, double* sum_ms, double* min_ms,
+                                    double* max_ms) {
+  if (!p) return RX_EINVAL;
+  double sum = 0, mn = 0, mx = 0;
+  for (size_t i = 0; i < p->n_timed; i++) {
+    HIPCHK(hipEventSynchronize(p->evs[i].second));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, p->evs[i].first, p->evs[i].second));
+    sum += ms;
+    mn = i == 0 ? ms : std::min<double>(mn, ms);
+    mx = std::max<double>(mx, ms);
+  }
+  if (n_launches) *n_launches = (uint32_t)p->n_timed;
+  if (sum_ms) *sum_ms = sum;
+  if (min_ms) *min_ms = mn;
+  if (max_ms) *max_ms = mx;
+  p->n_timed = 0;
   return RX_OK;
 }
 
 extern "C" int rx_plan_sync(rx_plan* p, double* kernel_ms) {
   if (!p) return RX_EINVAL;
   if (!p->launched) return RX_ESTATE;
-  HIPCHK(hipEventSynchronize(p->ev1));
+  if (p->n_timed == 0) { if (kernel_ms) *kernel_ms = p->last_ms; return RX_OK; }
+  auto& ev = p->evs[p->n_timed - 1];
+  HIPCHK(hipEventSynchronize(ev.second));
   float ms = 0;
-  HIPCHK(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+  HIPCHK(hipEventElapsedTime(&ms, ev.first, ev.second));
   p->last_ms = ms;
   if (kernel_ms) *kernel_ms = ms;
   return RX_OK;

@@ -57,7 +57,7 @@ class _Info(C.Structure):
 ABI_SYMBOLS = ["rx_strerror", "rx_last_hip_error", "rx_abi_version", "rx_nfa_load_coe", "rx_nfa_from_words",
                "rx_nfa_get_info", "rx_nfa_words", "rx_nfa_free", "rx_trace_load_mem", "rx_free", "rx_match",
                "rx_match_sharded", "rx_plan_create", "rx_plan_upload", "rx_plan_set_device_input",
-               "rx_plan_set_init_active", "rx_plan_launch", "rx_plan_sync", "rx_plan_download", "rx_plan_free",
+               "rx_plan_set_init_active", "rx_plan_launch", "rx_plan_sync", "rx_plan_kernel_times", "rx_plan_download", "rx_plan_free",
                "rx_device_count", "rx_device_name"]
 
 _lib = None
@@ -65,6 +65,26 @@ _lib = None
 
 def lib_path():
     return os.path.join(_HERE, "librxmatch.so")
+
+
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm bundles its own libamdhip64.so (same soname as /opt/rocm's).  Two HIP runtimes in one
+    process cannot share a GPU, so if torch is installed, map ITS runtime first: librxmatch.so and a later
+    (or earlier) `import torch` then resolve to the same library whatever the import order.  torch itself is
+    not imported here."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(p):
+        try:
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def lib():
@@ -76,6 +96,7 @@ def lib():
     if not os.path.exists(p):
         raise ImportError(f"{p} is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(p)
     vp, sz, u32, i32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int
     L.rx_strerror.restype = C.c_char_p
@@ -100,6 +121,8 @@ def lib():
     L.rx_plan_set_init_active.argtypes = [vp, vp]
     L.rx_plan_launch.argtypes = [vp]
     L.rx_plan_sync.argtypes = [vp, C.POINTER(C.c_double)]
+    L.rx_plan_kernel_times.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                       C.POINTER(C.c_double)]
     L.rx_plan_download.argtypes = [vp, C.POINTER(_Result)]
     L.rx_plan_free.argtypes = [vp]
     L.rx_plan_free.restype = None
@@ -319,6 +342,13 @@ class Plan:
         ms = C.c_double()
         _chk(lib().rx_plan_sync(self._h, C.byref(ms)), "rx_plan_sync")
         return ms.value
+
+    def kernel_times(self):
+        """-> (n_launches, sum_ms, min_ms, max_ms) of the launches since the previous call."""
+        n, s, mn, mx = C.c_uint32(), C.c_double(), C.c_double(), C.c_double()
+        _chk(lib().rx_plan_kernel_times(self._h, C.byref(n), C.byref(s), C.byref(mn), C.byref(mx)),
+             "rx_plan_kernel_times")
+        return n.value, s.value, mn.value, mx.value
 
     def download(self, want_total=True):
         wmc, wam, wfin = self.want

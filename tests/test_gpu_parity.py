@@ -1,0 +1,277 @@
+"""GPU parity: every HIP kernel, called through the C-ABI (librxmatch.so), must reproduce the CPU
+oracle BIT-EXACTLY (integer/byte/index work: no tolerance) — events, match counters, per-pass any-match
+bitmap, final active sets and the algorithmic-byte statistics.  Run with `-m gpu` on an MI355X."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from nfa_util import blowup_nfa, build_words, kat_ab, random_nfa
+
+pytestmark = pytest.mark.gpu
+G = json.load(open(os.path.join(GOLDEN, "golden.json")))
+N = 200000
+
+
+@pytest.fixture(scope="module")
+def kernels(rx):
+    return [rx.KERNEL_CSR_WAVE, rx.KERNEL_SYM_WAVE, rx.KERNEL_AUTO]
+
+
+@pytest.fixture(scope="module")
+def gpu_nfas(rx, automata):
+    return {name: rx.Nfa.from_words(W, size) for name, (W, size) in automata.items()}
+
+
+def check_equal(rx, orx, got, ref, what, stats=True):
+    assert got["n_events"] == ref["n_events"], what
+    assert not got["events_overflow"], what
+    assert np.array_equal(got["events"], ref["events"].astype(got["events"].dtype)), what
+    for k in ("match_count", "match_count_total", "anymatch", "final_active"):
+        if got.get(k) is not None and ref.get(k) is not None:
+            g = got[k][:, :ref[k].shape[1]] if k == "anymatch" else got[k]  # binding keeps >= 1 word per row
+            assert np.array_equal(g, ref[k]), (what, k)
+    if stats:
+        for k in ("n_passes", "n_events", "sum_active", "sum_edges", "alg_bytes"):
+            assert got["stats"][k] == ref["stats"][k], (what, k, got["stats"][k], ref["stats"][k])
+
+
+def test_loaded_native_library(rx):
+    """The HIP path is the one that runs: the in-tree .so is loaded and a device is visible."""
+    assert os.path.exists(rx.lib_path())
+    assert rx.host.device_count() >= 1
+    assert "gfx950" in rx.host.device_name(0)
+    maps = open("/proc/self/maps").read()
+    assert "librxmatch.so" in maps
+
+
+def test_kat_ab(rx, orx, kernels):
+    W, size = kat_ab()
+    nfa = rx.Nfa.from_words(W)
+    data = np.frombuffer(b"xabab", np.uint8)
+    for mode in (rx.MODE_FULL, rx.MODE_TB_COMPAT):
+        ref = orx.match_batch(W, size, data, mode=mode, want_match_count=True)
+        for kern in kernels:
+            got = rx.match(nfa, data, mode=mode, kernel=kern, want_match_count=True, collect_stats=True)
+            check_equal(rx, orx, got, ref, ("ab", mode, kern))
+    got = rx.match(nfa, data, kernel=rx.KERNEL_AUTO, want_match_count=True)
+    assert [(int(e["k"]), int(e["state"])) for e in got["events"]] == [(3, 3), (5, 3)]
+
+
+@pytest.mark.parametrize("key", sorted(G["tb_compat"]))
+def test_shipped_traces_single_stream(rx, orx, automata, traces, gpu_nfas, kernels, key):
+    """BASELINE configs[0]/[1]: each shipped trace as ONE stream, tb-compat, vs golden digests + oracle."""
+    name, lh = key.split(":")
+    W, size = automata[name]
+    data = traces[(name, lh)][:N]
+    ref = orx.match_batch(W, size, data, mode=orx.MODE_TB_COMPAT, nthreads=1, want_match_count=True)
+    g = G["tb_compat"][key]
+    for kern in kernels:
+        got = rx.match(gpu_nfas[name], data, mode=rx.MODE_TB_COMPAT, kernel=kern, want_match_count=True,
+                       collect_stats=True)
+        check_equal(rx, orx, got, ref, (key, kern))
+        assert orx.h_match_count(got["match_count"][0]) == g["H_mc"]
+        assert orx.h_events(got["events"]) == g["H_ev"]
+        assert orx.bits_to_states(got["final_active"][0]) == g["final_active"]
+        assert got["stats"]["alg_bytes"] == g["alg_bytes"]
+
+
+@pytest.mark.parametrize("name", ["l7", "snort_16"])
+def test_testbench_pair_and_report(rx, orx, automata, traces, gpu_nfas, name):
+    """What Blk_Mem_tb does: lo+hi in lock-step, full mode too, and the $display report text."""
+    W, size = automata[name]
+    lo, hi = traces[(name, "lo")], traces[(name, "hi")]
+    r = rx.testbench.run(gpu_nfas[name], lo, hi)
+    c = orx.tb_cycle(W, size, lo[:N + 1], hi[:N + 1], N, skip_idle=True)
+    assert np.array_equal(r["match_count"][0], c["match_count"])
+    assert np.array_equal(r["match_count"][1], c["match_count_2"])
+    want = rx.testbench.format_report(c["match_count"], c["match_count_2"])
+    assert r["report"] == want and "match_count_2[" in want
+    first = want.splitlines()[0]
+    top = int(np.nonzero(c["match_count"])[0].max())
+    assert first == f"match_count[{top:11d}] = {int(c['match_count'][top]) & 1023:4d}"
+    rows = np.stack([lo[:N], hi[:N]])
+    ref = orx.match_batch(W, size, rows, mode=orx.MODE_FULL, want_match_count=True)
+    got = rx.match(gpu_nfas[name], rows, mode=rx.MODE_FULL, want_match_count=True, collect_stats=True)
+    check_equal(rx, orx, got, ref, (name, "pair full"))
+
+
+@pytest.mark.parametrize("workload", ["T", "U"])
+def test_synthetic_batches(rx, orx, automata, traces, gpu_nfas, kernels, workload):
+    """BASELINE configs[2] shape at oracle-sized scale: 1536 streams x 1024 B, both distributions."""
+    W, size = automata["snort_16"]
+    wl = rx.workloads
+    if workload == "T":
+        rows = wl.trace_windows(traces[("snort_16", "lo")], traces[("snort_16", "hi")], 1536, 1024, first=1000)
+    else:
+        rows = wl.uniform(1536, 1024, first=77)
+    ref = orx.match_batch(W, size, rows, want_match_count=True)
+    if workload == "T":
+        assert ref["n_events"] > 100
+    for kern in kernels:
+        got = rx.match(gpu_nfas["snort_16"], rows, kernel=kern, want_match_count=True, collect_stats=True)
+        check_equal(rx, orx, got, ref, (workload, kern))
+
+
+def test_ragged_and_edge_shapes(rx, orx, automata, traces, gpu_nfas, kernels):
+    """Empty / 1-byte / non-multiple-of-4 / chunk-boundary lengths, odd strides, unaligned rows."""
+    W, size = automata["snort_16"]
+    hi = traces[("snort_16", "hi")]
+    for sl in (0, 1, 2, 3, 5, 255, 256, 257, 511, 513, 1023):
+        for ns in (1, 3, 67):
+            rows = np.stack([hi[(7 * s) % 900:(7 * s) % 900 + sl] for s in range(ns)]) if sl else np.zeros((ns, 0), np.uint8)
+            for mode in (rx.MODE_FULL, rx.MODE_TB_COMPAT):
+                ref = orx.match_batch(W, size, rows, mode=mode)
+                for kern in kernels:
+                    got = rx.match(gpu_nfas["snort_16"], rows, mode=mode, kernel=kern, collect_stats=True)
+                    check_equal(rx, orx, got, ref, (sl, ns, mode, kern))
+    # strided view: rows start at odd addresses (stride 301, offset 1)
+    buf = np.zeros(40 * 301 + 8, np.uint8)
+    buf[:] = np.resize(hi[:5000], buf.size)
+    view = np.lib.stride_tricks.as_strided(buf[1:], shape=(40, 298), strides=(301, 1))
+    ref = orx.match_batch(W, size, np.ascontiguousarray(view))
+    for kern in kernels:
+        got = rx.match(gpu_nfas["snort_16"], view, kernel=kern, collect_stats=True)
+        check_equal(rx, orx, got, ref, ("strided", kern))
+
+
+def test_device_input_unaligned(rx, orx, automata, traces, gpu_nfas, kernels):
+    """rx_plan_set_device_input with a caller-owned HBM buffer whose rows are NOT 4-byte aligned."""
+    torch = pytest.importorskip("torch")
+    W, size = automata["snort_16"]
+    hi = traces[("snort_16", "hi")]
+    ns, sl, stride = 50, 333, 335
+    host = np.zeros(ns * stride + 3, np.uint8)
+    rows = np.stack([hi[s * 11:s * 11 + sl] for s in range(ns)])
+    for s in range(ns):
+        host[1 + s * stride:1 + s * stride + sl] = rows[s]
+    d = torch.from_numpy(host).cuda()
+    ref = orx.match_batch(W, size, rows)
+    for kern in kernels:
+        p = rx.Plan(gpu_nfas["snort_16"], ns, sl, kernel=kern, device=0, collect_stats=True)
+        p.set_device_input(d.data_ptr() + 1, ns, sl, stride, keepalive=d)
+        p.launch()
+        p.launch()  # relaunching a resident plan gives the same answer
+        got = p.download()
+        check_equal(rx, orx, got, ref, ("device input", kern))
+        n, s_ms, mn, mx = p.kernel_times()
+        assert n == 2 and 0 < mn <= mx
+        p.close()
+
+
+def test_chunked_streaming_chain(rx, orx, automata, traces, gpu_nfas, kernels):
+    """final_active -> init_active across calls + k_base == one uninterrupted run."""
+    W, size = automata["snort_16"]
+    hi, lo = traces[("snort_16", "hi")], traces[("snort_16", "lo")]
+    rows = np.stack([hi[:6000], lo[:6000], hi[1000:7000]])
+    whole = orx.match_batch(W, size, rows)
+    cut = 2500
+    for kern in kernels:
+        a = rx.match(gpu_nfas["snort_16"], rows[:, :cut], kernel=kern)
+        b = rx.match(gpu_nfas["snort_16"], rows[:, cut:], kernel=kern, init_active=a["final_active"], k_base=cut)
+        ev_a = a["events"][a["events"]["k"] < cut]
+        ev = np.concatenate([ev_a, b["events"]])
+        ev = ev[np.lexsort((ev["state"], ev["k"], ev["stream"]))]
+        assert np.array_equal(ev, whole["events"].astype(ev.dtype)), kern
+        assert np.array_equal(b["final_active"], whole["final_active"]), kern
+
+
+def test_active_set_larger_than_list_capacity(rx, orx, kernels):
+    """|S_k| = 300 > RX_LIST_CAP: the dense (bitmask-walk) form must give identical results."""
+    W, size = blowup_nfa(300)
+    nfa = rx.Nfa.from_words(W)
+    rng = np.random.default_rng(5)
+    rows = rng.choice(np.array([0x41, 0x42, 0x43, 0x44], np.uint8), size=(9, 64), p=[0.45, 0.05, 0.45, 0.05])
+    rows[0, :6] = [0x43, 0x41, 0x41, 0x43, 0x42, 0x43]
+    ref = orx.match_batch(W, size, rows, want_match_count=True)
+    assert ref["stats"]["sum_active"] > 300 * 20 and ref["n_events"] >= 1
+    for kern in kernels:
+        got = rx.match(nfa, rows, kernel=kern, want_match_count=True, collect_stats=True)
+        check_equal(rx, orx, got, ref, ("blowup", kern))
+
+
+def test_random_automata(rx, orx, kernels):
+    """Seeded random NFAs (unsorted rows, multi-target symbols, self loops, sinks) x random streams."""
+    rng = np.random.default_rng(20261004)
+    for trial in range(40):
+        size = int(rng.integers(2, 400))
+        alpha = int(rng.integers(2, 12))
+        W, size = random_nfa(rng, size, max_deg=int(rng.integers(1, 20)), alphabet=alpha, dense_rows=int(rng.integers(0, 3)))
+        nfa = rx.Nfa.from_words(W)
+        ns, sl = int(rng.integers(1, 40)), int(rng.integers(0, 300))
+        rows = rng.integers(0, alpha, size=(ns, sl), dtype=np.uint8)
+        mode = int(trial & 1)
+        ref = orx.match_batch(W, size, rows, mode=mode, want_match_count=True)
+        for kern in kernels:
+            got = rx.match(nfa, rows, mode=mode, kernel=kern, want_match_count=True, collect_stats=True)
+            check_equal(rx, orx, got, ref, ("random", trial, kern))
+
+
+def test_events_capacity_overflow(rx, orx, automata, traces, gpu_nfas):
+    W, size = automata["snort_16"]
+    rows = np.stack([traces[("snort_16", "hi")][:4000]] * 8)
+    ref = orx.match_batch(W, size, rows)
+    got = rx.match(gpu_nfas["snort_16"], rows, events_cap=10)
+    assert got["n_events"] == ref["n_events"] > 10 and got["events_overflow"] and len(got["events"]) == 10
+    assert np.array_equal(got["match_count_total"], ref["match_count_total"])  # counters never overflow
+    none = rx.match(gpu_nfas["snort_16"], rows, events_cap=0, want_anymatch=True)
+    assert none["n_events"] == ref["n_events"] and np.array_equal(none["anymatch"], ref["anymatch"])
+
+
+def test_full_size_config3_properties(rx, orx, automata, traces, gpu_nfas, kernels):
+    """BASELINE configs[2] at full size (65 536 x 1 KB, distribution T): all kernels agree bit-for-bit on
+    every output, a seeded sample of 3 072 streams equals the oracle, and size-independent invariants
+    hold (event order, counters = histogram of events, any-match bits = event passes)."""
+    W, size = automata["snort_16"]
+    wl = rx.workloads
+    ns, sl = 65536, 1024
+    rows = wl.trace_windows(traces[("snort_16", "lo")], traces[("snort_16", "hi")], ns, sl)
+    outs = [rx.match(gpu_nfas["snort_16"], rows, kernel=k, events_cap=1 << 21, collect_stats=True) for k in kernels]
+    a = outs[0]
+    for b in outs[1:]:
+        for k in ("events", "match_count_total", "anymatch", "final_active"):
+            assert np.array_equal(a[k], b[k]), k
+        assert {k: v for k, v in a["stats"].items() if k in ("n_events", "sum_active", "sum_edges", "alg_bytes")} == \
+               {k: v for k, v in b["stats"].items() if k in ("n_events", "sum_active", "sum_edges", "alg_bytes")}
+    ev = a["events"]
+    assert a["n_events"] == len(ev) > 10000
+    order = np.lexsort((ev["state"], ev["k"], ev["stream"]))
+    assert np.array_equal(order, np.arange(len(ev)))
+    assert np.array_equal(np.bincount(ev["state"], minlength=size).astype(np.uint64), a["match_count_total"])
+    bits = np.zeros_like(a["anymatch"])
+    np.bitwise_or.at(bits, (ev["stream"], ev["k"] >> 5), (np.uint32(1) << (ev["k"] & 31)).astype(np.uint32))
+    assert np.array_equal(bits, a["anymatch"])
+    rng = np.random.default_rng(3)
+    pick = np.sort(rng.choice(ns, size=3072, replace=False))
+    ref = orx.match_batch(W, size, rows[pick])
+    sel = ev[np.isin(ev["stream"], pick)]
+    remap = np.searchsorted(pick, sel["stream"]).astype(np.uint32)
+    sel = sel.copy()
+    sel["stream"] = remap
+    assert np.array_equal(sel, ref["events"].astype(sel.dtype))
+    assert np.array_equal(a["final_active"][pick], ref["final_active"])
+    assert np.array_equal(a["anymatch"][pick], ref["anymatch"])
+
+
+def test_sharded_entry_point_single_device(rx, orx, automata, traces, gpu_nfas):
+    """rx_match_sharded with the one visible device listed twice: the partition/merge path of the C-ABI."""
+    W, size = automata["snort_16"]
+    rows = rx.workloads.trace_windows(traces[("snort_16", "lo")], traces[("snort_16", "hi")], 301, 700)
+    ref = orx.match_batch(W, size, rows, want_match_count=True)
+    got = rx.match_sharded(gpu_nfas["snort_16"], rows, devices=[0, 0, 0], want_match_count=True, collect_stats=True)
+    check_equal(rx, orx, got, ref, "sharded")
+
+
+def test_report_cli(rx, orx, automata, traces):
+    """rx_report (C++ caller of the C-ABI) prints the testbench's lines for the shipped l7 pair."""
+    import subprocess
+    from conftest import DATA
+    exe = os.path.join(os.path.dirname(rx.lib_path()), "rx_report")
+    out = subprocess.check_output([exe, os.path.join(DATA, "CSR_BlockMem.coe"),
+                                   os.path.join(DATA, "input_trace_lo_l-7_filter.mem"),
+                                   os.path.join(DATA, "input_trace_hi_l-7_filter.mem")], stderr=subprocess.DEVNULL).decode()
+    W, size = automata["l7"]
+    c = orx.tb_cycle(W, size, traces[("l7", "lo")][:N + 1], traces[("l7", "hi")][:N + 1], N, skip_idle=True)
+    assert out.strip() == rx.testbench.format_report(c["match_count"], c["match_count_2"])
