@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--stream-len", type=int, default=1024)
     ap.add_argument("--workload", choices=["T", "U"], default="T")
     ap.add_argument("--kernel", default="auto", choices=["auto", "csr_wave", "sym_wave", "sym_group"])
+    ap.add_argument("--group-lanes", type=int, default=0)
     ap.add_argument("--cpu-sample-streams", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--all-kernels", action="store_true", help="also time the other kernels (extra keys)")
@@ -99,12 +100,13 @@ def main():
     h2d_s = time.perf_counter() - t_h2d0
     stream = torch.cuda.current_stream().cuda_stream
     plan = rx.Plan(nfa, ns, sl, mode=rx.MODE_FULL, kernel=kern, device=local, stream=stream, events_cap=1 << 22,
-                   want_match_count=False, want_anymatch=True, want_final=True)
+                   want_match_count=False, want_anymatch=True, want_final=True, group_lanes=a.group_lanes)
     plan.set_device_input(d_rows.data_ptr(), ns, sl, sl, keepalive=d_rows)
 
     # algorithmic bytes of one launch: collect_stats build of the same kernel, untimed
     splan = rx.Plan(nfa, ns, sl, mode=rx.MODE_FULL, kernel=kern, device=local, stream=stream, events_cap=1 << 22,
-                    want_match_count=False, want_anymatch=True, want_final=True, collect_stats=True)
+                    want_match_count=False, want_anymatch=True, want_final=True, collect_stats=True,
+                    group_lanes=a.group_lanes)
     splan.set_device_input(d_rows.data_ptr(), ns, sl, sl, keepalive=d_rows)
     splan.launch()
     sres = splan.download()
@@ -169,8 +171,11 @@ def main():
 
     if a.all_kernels:
         extra = {}
-        for name, kid in (("csr_wave", rx.KERNEL_CSR_WAVE), ("sym_wave", rx.KERNEL_SYM_WAVE)):
-            p2 = rx.Plan(nfa, ns, sl, mode=rx.MODE_FULL, kernel=kid, device=local, stream=stream, events_cap=1 << 22)
+        for name, kid, gl in (("csr_wave", rx.KERNEL_CSR_WAVE, 0), ("sym_wave", rx.KERNEL_SYM_WAVE, 0),
+                              ("sym_group4", rx.KERNEL_SYM_GROUP, 4), ("sym_group8", rx.KERNEL_SYM_GROUP, 8),
+                              ("sym_group16", rx.KERNEL_SYM_GROUP, 16)):
+            p2 = rx.Plan(nfa, ns, sl, mode=rx.MODE_FULL, kernel=kid, device=local, stream=stream, events_cap=1 << 22,
+                         group_lanes=gl)
             p2.set_device_input(d_rows.data_ptr(), ns, sl, sl, keepalive=d_rows)
             time_kernel(p2, 2)
             avg, mn, mx = time_kernel(p2, max(a.steps // 2, 3))

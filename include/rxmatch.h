@@ -97,7 +97,9 @@ enum {
   RX_KERNEL_AUTO = 0,     /* fastest parity-checked kernel for this automaton            */
   RX_KERNEL_CSR_WAVE = 1, /* wavefront-per-stream over the state-major CSR as loaded     */
   RX_KERNEL_SYM_WAVE = 2, /* wavefront-per-stream over the per-(state,symbol) slice index */
-  RX_KERNEL_SYM_GROUP = 3 /* 16-lane group per stream (4 streams per wavefront), slice index */
+  RX_KERNEL_SYM_GROUP = 3 /* G lanes per stream (64/G streams per wavefront), slice index;
+                             streams whose active set outgrows the group's list are finished by
+                             RX_KERNEL_SYM_WAVE in the same call                            */
 };
 
 typedef struct rx_opts {
@@ -108,7 +110,7 @@ typedef struct rx_opts {
   void* stream;         /* hipStream_t to launch on; NULL = the default stream           */
   uint64_t k_base;      /* added to every reported pass index (chunked streaming)        */
   uint32_t collect_stats; /* !=0: also accumulate rx_stats.sum_active/sum_edges on device */
-  uint32_t reserved;
+  uint32_t group_lanes;   /* RX_KERNEL_SYM_GROUP: lanes per stream, 4 / 8 / 16; 0 = default   */
 } rx_opts;
 
 /* One accept pulse: `state` was active and accepting in pass `k` of stream `stream`.

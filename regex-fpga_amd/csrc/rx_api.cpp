@@ -205,6 +205,7 @@ struct rx_plan {
   uint32_t* d_final = nullptr;
   uint32_t* d_init = nullptr;
   bool have_init = false;
+  uint32_t *d_spill_streams = nullptr, *d_spill_k = nullptr, *d_spill_rows = nullptr;
   size_t am_stride = 0;
   // current batch
   size_t n_streams = 0, stream_len = 0, stride = 0;
@@ -291,6 +292,9 @@ extern "C" void rx_plan_free(rx_plan* p) {
   (void)hipFree(p->d_am);
   (void)hipFree(p->d_final);
   (void)hipFree(p->d_init);
+  (void)hipFree(p->d_spill_streams);
+  (void)hipFree(p->d_spill_k);
+  (void)hipFree(p->d_spill_rows);
   for (auto& e : p->evs) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (have_prev) (void)hipSetDevice(prev);
   delete p;
@@ -389,9 +393,24 @@ extern "C" int rx_plan_launch(rx_plan* p) {
   a.anymatch = p->want_am ? p->d_am : nullptr;
   a.anymatch_stride = (uint32_t)p->am_stride;
   a.final_active = p->want_final ? p->d_final : nullptr;
-  rc = rx_pick_launch(p->opts.kernel, h.size, a.n_streams, p->tab.cu_count, p->tab.lds_per_cu, &a, &p->cfg);
+  uint32_t kernel = p->opts.kernel;
+  // a caller-supplied start set is a bitmask row: that is the wave kernel's dense form
+  if (p->have_init && (kernel == RX_KERNEL_AUTO || kernel == RX_KERNEL_SYM_GROUP)) kernel = RX_KERNEL_SYM_WAVE;
+  p->cfg.group_lanes = p->opts.group_lanes;
+  rc = rx_pick_launch(kernel, h.size, a.n_streams, p->tab.cu_count, p->tab.lds_per_cu, &a, &p->cfg);
   if (rc) return rc;
   p->cfg.stats = p->opts.collect_stats != 0;
+  if (p->cfg.kernel == RX_KERNEL_SYM_GROUP) {
+    if (!p->d_spill_rows) {  // hand-off area group kernel -> wave kernel, sized so that it cannot overflow
+      HIPCHK(hipMalloc((void**)&p->d_spill_streams, p->max_streams * sizeof(uint32_t)));
+      HIPCHK(hipMalloc((void**)&p->d_spill_k, p->max_streams * sizeof(uint32_t)));
+      HIPCHK(hipMalloc((void**)&p->d_spill_rows, p->max_streams * (size_t)a.nw64x2 * sizeof(uint32_t)));
+    }
+    a.spill_count = p->d_counters + 3;
+    a.spill_streams = p->d_spill_streams;
+    a.spill_k = p->d_spill_k;
+    a.spill_rows = p->d_spill_rows;
+  }
 
   HIPCHK(hipMemsetAsync(p->d_counters, 0, 4 * sizeof(unsigned long long), p->stream));
   HIPCHK(hipMemsetAsync(p->d_mct, 0, (size_t)h.size * sizeof(unsigned long long), p->stream));
@@ -404,7 +423,9 @@ extern "C" int rx_plan_launch(rx_plan* p) {
     p->evs.emplace_back(a0, a1);
   }
   auto& ev = p->evs[p->n_timed];
-  HIPCHK(hipEventRecord(ev.first, p->stream));  // brackets the match kernel only, on its own stream
+  HIPCHK(hipEventRecord(ev.first, p->stream));  // brackets the match kernel(s) only, on their own stream
+  if (p->cfg.kernel == RX_KERNEL_SYM_GROUP && p->want_final)  // the group kernel ORs bits into zeroed rows
+    HIPCHK(hipMemsetAsync(p->d_final, 0, p->n_streams * (size_t)a.nw64x2 * sizeof(uint32_t), p->stream));
   hipError_t e = (hipError_t)rx_launch(a, p->cfg, p->stream);
   if (e != hipSuccess) return hip_fail(e, "kernel launch");
   HIPCHK(hipEventRecord(ev.second, p->stream));
@@ -469,7 +490,7 @@ extern "C" int rx_plan_download(rx_plan* p, rx_result* res) {
   st.n_events = cnt[0];
   st.kernel_ms = p->last_ms;
   st.kernel_used = p->cfg.kernel;
-  st.n_launches = 1;
+  st.n_launches = p->cfg.kernel == RX_KERNEL_SYM_GROUP ? 2 : 1;
   if (p->cfg.stats) {
     st.sum_active = cnt[1];
     st.sum_edges = cnt[2];

@@ -58,10 +58,20 @@ struct RxParams {
   uint32_t* final_active;       // [n_streams][nw64x2] or null
   // LDS carve
   uint32_t lds_words_per_stream;
+  // spill hand-off: group kernel -> wave kernel (streams whose active set outgrew the group's list)
+  unsigned long long* spill_count;  // == &counters[3]
+  uint32_t* spill_streams;          // [n_streams] stream id per spill slot
+  uint32_t* spill_k;                // [n_streams] pass at which the stream must be resumed
+  uint32_t* spill_rows;             // [n_streams][nw64x2] S_k of the spilled stream as a bitmask row
+  uint32_t resume;                  // wave kernel: 1 = walk the spill list instead of all streams
 };
+
+static constexpr uint32_t RX_GROUP_CAP = 32;     // group kernel: active-list capacity per stream
+static constexpr uint32_t RX_GROUP_FILTER_WORDS = 32;  // 1024-bit hashed dedup filter per stream
 
 struct RxLaunchCfg {
   uint32_t kernel;         // RX_KERNEL_* (resolved, never AUTO)
+  uint32_t group_lanes;    // SYM_GROUP: lanes per stream (4 or 8)
   uint32_t block_threads;
   uint32_t grid_blocks;
   uint32_t lds_bytes;      // dynamic LDS per block

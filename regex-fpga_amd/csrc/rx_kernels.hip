@@ -116,16 +116,16 @@ __device__ __forceinline__ void emit_target(StreamState& st, bool pred, uint32_t
   }
 }
 
-__device__ __forceinline__ void stream_reset(const RxParams& p, StreamState& st, uint32_t* my, uint32_t stream,
-                                             uint32_t lane) {
+__device__ __forceinline__ void stream_reset(const RxParams& p, StreamState& st, uint32_t* my,
+                                             const uint32_t* init_row, uint32_t lane) {
   st.cb = my;
   st.nb = my + p.nw32;
   st.clist = st.nb + p.nw32;
   st.nlist = st.clist + RX_LIST_CAP;
   for (uint32_t w = lane; w < 2u * p.nw32; w += 64u) my[w] = 0u;
   st.n_next = 0;
-  if (p.init_active) {  // chunked streaming: resume from a caller-supplied active set
-    const uint32_t* row = p.init_active + (size_t)stream * p.nw64x2;
+  if (init_row) {  // chunked streaming / spill hand-off: resume from a given active set
+    const uint32_t* row = init_row;
     for (uint32_t w = lane; w < p.nw32; w += 64u) st.cb[w] = row[w];
     st.dense = true;
     st.n_cur = 0;
@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(256) rx_csr_wave_kernel(const RxParams p) {
 
   for (uint32_t stream = blockIdx.x * wpb + wib; stream < p.n_streams; stream += gridDim.x * wpb) {
     StreamState st;
-    stream_reset(p, st, my, stream, lane);
+    stream_reset(p, st, my, p.init_active ? p.init_active + (size_t)stream * p.nw64x2 : nullptr, lane);
     ByteFeed feed;
     feed.base = p.bytes + (size_t)stream * p.stride;
     feed.len = p.stream_len;
@@ -298,22 +298,37 @@ __global__ void __launch_bounds__(256) rx_sym_wave_kernel(const RxParams p) {
   const uint32_t* __restrict__ symidx = p.symidx;
   const uint32_t* __restrict__ ovf = p.ovf;
   unsigned long long st_active = 0, st_edges = 0;
+  // resume mode: finish the streams the group kernel handed off (their active set outgrew its list)
+  uint32_t total = p.n_streams;
+  if (p.resume) {
+    const unsigned long long n = *p.spill_count;
+    total = n < p.n_streams ? (uint32_t)n : p.n_streams;
+  }
 
-  for (uint32_t stream = blockIdx.x * wpb + wib; stream < p.n_streams; stream += gridDim.x * wpb) {
+  for (uint32_t idx = blockIdx.x * wpb + wib; idx < total; idx += gridDim.x * wpb) {
+    uint32_t stream = idx, k0 = 0;
+    const uint32_t* init_row = p.init_active ? p.init_active + (size_t)idx * p.nw64x2 : nullptr;
+    if (p.resume) {
+      stream = p.spill_streams[idx];
+      k0 = p.spill_k[idx];
+      init_row = p.spill_rows + (size_t)idx * p.nw64x2;
+    }
     StreamState st;
-    stream_reset(p, st, my, stream, lane);
+    stream_reset(p, st, my, init_row, lane);
     ByteFeed feed;
     feed.base = p.bytes + (size_t)stream * p.stride;
     feed.len = p.stream_len;
     feed.aligned = ((reinterpret_cast<uintptr_t>(feed.base)) & 3u) == 0;
-    uint32_t cur_word = 0, nxt_word = feed.load_chunk(0, lane);
-    uint32_t am_word = 0;
+    uint32_t cur_word = 0, nxt_word = feed.load_chunk(k0 >> 8, lane);
+    // the hand-off pass already emitted its accept pulses; keep the bits of its partial bitmap word
+    uint32_t am_word = (p.resume && p.anymatch) ? p.anymatch[(size_t)stream * p.anymatch_stride + (k0 >> 5)] : 0u;
 
-    for (uint32_t k = 0; k < p.n_passes; k++) {
+    for (uint32_t k = k0; k < p.n_passes; k++) {
       const bool consume = k < p.n_consume;
+      const bool pulses = !(p.resume && k == k0);
       uint32_t c = 0;
       if (consume) {
-        if ((k & 255u) == 0) {
+        if ((k & 255u) == 0 || k == k0) {
           cur_word = nxt_word;
           nxt_word = feed.load_chunk((k >> 8) + 1u, lane);
         }
@@ -322,9 +337,9 @@ __global__ void __launch_bounds__(256) rx_sym_wave_kernel(const RxParams p) {
       for_each_active<true>(p, st, lane, [&](bool valid, uint32_t e) {
         const uint32_t s = e & RXE_TGT_MASK;
         const bool acc = valid && (e & RXE_ACCEPT);
-        emit_events(p, acc, s, stream, k, lane, am_word);
+        if (pulses) emit_events(p, acc, s, stream, k, lane, am_word);
         if (!consume) return;
-        if (STATS && valid) { st_active += 1; st_edges += rp[s + 1] - rp[s]; }
+        if (STATS && valid && pulses) { st_active += 1; st_edges += rp[s + 1] - rp[s]; }  // hand-off pass already counted
         // the current byte's slice of row s: one dword
         const uint32_t ent = (valid && !acc) ? symidx[(size_t)s * 256u + c] : 0u;
         if (__ballot(ent & RXE_SELF)) emit_target(st, (ent & RXE_SELF) != 0, s, lane);
@@ -355,6 +370,221 @@ __global__ void __launch_bounds__(256) rx_sym_wave_kernel(const RxParams p) {
   }
 }
 
+// =================================================================================================
+// Kernel 3: G lanes per stream, 64/G streams per wavefront, slice index
+// =================================================================================================
+// The snort_16 / l7 active sets are tiny (1-4 states per byte), so a whole wavefront per stream
+// leaves ~60 lanes idle and the kernel is bound by instruction issue, not by memory.  Here a
+// wavefront carries 64/G streams in lock-step: the G lanes of a group take the group's active-list
+// entries G at a time, every lane gathers "its" (state, byte) slice dword, and insertions use
+//   * a 1024-bit hashed filter per stream in LDS (ds_or_rtn_b32): bit clear => certainly new;
+//   * __ballot + popcount of the group's nibble for list slots;
+//   * bit already set (true duplicate or hash collision) => that lane scans the group's next list
+//     (rare; one lane per group at a time so two equal targets cannot both be appended).
+// A stream whose next set would exceed RX_GROUP_CAP is handed to the wavefront-per-stream kernel in
+// resume mode (S_k as a bitmask row + k), so results stay exact for any automaton / input.
+template <int G>
+struct GroupLayout {
+  static constexpr uint32_t FW = RX_GROUP_FILTER_WORDS;
+  static constexpr uint32_t CAP = RX_GROUP_CAP;
+  static constexpr uint32_t BUFW = 4u * G;  // byte window: 16 B per lane
+  static constexpr uint32_t RAW = FW + 2u * CAP + BUFW;
+  // region stride == G (mod 2G): within a 32-lane half the groups' list slots (g*REGION + j) fall on
+  // distinct LDS banks, and equal filter words of different streams are at most 2-way conflicted
+  static constexpr uint32_t PAD = ((G + 2u * G * 64u) - RAW) % (2u * G);
+  static constexpr uint32_t REGION = RAW + PAD;
+  static constexpr uint32_t SPW = 64u / G;  // streams per wavefront
+};
+
+template <int G, bool STATS>
+__global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
+  using L = GroupLayout<G>;
+  constexpr uint32_t GMASK = (G == 32) ? 0xFFFFFFFFu : ((1u << G) - 1u);
+  constexpr uint32_t CH = 16u * G;  // bytes of each stream held in LDS at a time
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wib = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const uint32_t g = lane / G, j = lane % G;
+  const uint32_t gshift = lane & ~(uint32_t)(G - 1);
+  const uint32_t below = (1u << j) - 1u;
+  uint32_t* reg = lds + ((size_t)wib * L::SPW + g) * L::REGION;
+  uint32_t* filt = reg;
+  uint32_t* lists = reg + L::FW;                 // [2][CAP]
+  uint32_t* bufw = lists + 2u * L::CAP;          // [BUFW] byte window
+  const uint8_t* buf8 = reinterpret_cast<const uint8_t*>(bufw);
+  const uint32_t* __restrict__ rp = p.words;
+  const uint32_t* __restrict__ symidx = p.symidx;
+  const uint32_t* __restrict__ ovf = p.ovf;
+  unsigned long long st_active = 0, st_edges = 0;
+
+  const uint32_t wave = blockIdx.x * wpb + wib;
+  const uint32_t stream = wave * L::SPW + g;
+  bool alive = stream < p.n_streams;
+  const uint8_t* base = p.bytes + (size_t)(alive ? stream : 0) * p.stride;
+  const bool aligned = (reinterpret_cast<uintptr_t>(base) & 3u) == 0;
+
+  // 16 bytes of this lane's share of chunk `chunk`
+  auto load16 = [&](uint32_t chunk, uint32_t (&w)[4]) {
+    const uint32_t off = chunk * CH + j * 16u;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint32_t o = off + 4u * q;
+      uint32_t v = 0;
+      if (alive) {
+        if (aligned && o + 4u <= p.stream_len) v = *reinterpret_cast<const uint32_t*>(base + o);
+        else
+          for (uint32_t b = 0; b < 4; b++)
+            if (o + b < p.stream_len) v |= (uint32_t)base[o + b] << (8u * b);
+      }
+      w[q] = v;
+    }
+  };
+
+  for (uint32_t w = j; w < L::FW; w += G) filt[w] = 0u;
+  if (j == 0) lists[0] = p.state0_entry;  // FPGA.v:134-147: current = {state 0}
+  uint32_t n_cur = 1, n_next = 0, tog = 0, am_word = 0;
+  uint32_t nxt[4];
+  load16(0, nxt);
+  wave_sync();
+
+  for (uint32_t k = 0; k < p.n_passes; k++) {
+    const bool consume = k < p.n_consume;
+    uint32_t c = 0;
+    if (consume) {
+      if ((k % CH) == 0) {  // refill the LDS byte window, fetch the next one into registers
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < 4; q++) bufw[j * 4u + q] = nxt[q];
+        load16(k / CH + 1u, nxt);
+        wave_sync();
+      }
+      c = buf8[k % CH];  // input_char of this group's stream (same address in all G lanes: broadcast)
+    }
+    uint32_t* clist = lists + tog * L::CAP;
+    uint32_t* nlist = lists + (tog ^ 1u) * L::CAP;
+    n_next = 0;
+
+    // insert target entry t into this group's next set; wave-uniform call
+    auto insert = [&](bool pred, uint32_t t) {
+      const uint32_t h = t & (32u * L::FW - 1u);
+      const uint32_t bit = 1u << (h & 31u);
+      uint32_t old = 0;
+      if (pred) old = atomicOr(&filt[h >> 5], bit);
+      const bool fresh = pred && (old & bit) == 0;
+      const bool maybe = pred && (old & bit) != 0;
+      const uint32_t gb = (uint32_t)(__ballot(fresh) >> gshift) & GMASK;
+      const uint32_t slot = n_next + (uint32_t)__popc(gb & below);
+      if (fresh && slot < L::CAP) nlist[slot] = t;
+      n_next += (uint32_t)__popc(gb);
+      const uint64_t mm = __ballot(maybe);
+      if (mm) {  // rare: true duplicate or filter collision -> exact check against the list
+        uint32_t gm = (uint32_t)(mm >> gshift) & GMASK;
+        wave_sync();
+        while (__ballot(gm != 0)) {
+          const bool mine = maybe && gm != 0 && (gm & (0u - gm)) == (1u << j);
+          bool found = false;
+          if (mine) {
+            const uint32_t lim = n_next < L::CAP ? n_next : L::CAP;
+            for (uint32_t q = 0; q < lim; q++) found |= ((nlist[q] ^ t) & RXE_TGT_MASK) == 0;
+          }
+          const bool app = mine && !found;
+          const uint32_t ga = (uint32_t)(__ballot(app) >> gshift) & GMASK;
+          if (app && n_next < L::CAP) nlist[n_next] = t;
+          n_next += ga ? 1u : 0u;
+          gm &= gm - 1u;
+          wave_sync();
+        }
+      }
+    };
+
+    for (uint32_t it = 0;; it++) {
+      const uint32_t idx = it * G + j;
+      const bool valid = alive && idx < n_cur;
+      if (__ballot(valid) == 0) break;
+      const uint32_t e = valid ? clist[idx] : 0u;
+      const uint32_t s = e & RXE_TGT_MASK;
+      const bool acc = valid && (e & RXE_ACCEPT);
+      {  // accept pulses
+        const uint64_t ma = __ballot(acc);
+        if (ma) {
+          uint32_t dummy = 0;
+          emit_events(p, acc, s, stream, k, lane, dummy);
+          if ((uint32_t)(ma >> gshift) & GMASK) am_word |= 1u << (k & 31u);
+        }
+      }
+      if (!consume) continue;
+      if (STATS && valid) { st_active += 1; st_edges += rp[s + 1] - rp[s]; }
+      const uint32_t ent = (valid && !acc) ? symidx[(size_t)s * 256u + c] : 0u;
+      if (__ballot(ent & RXE_SELF)) insert((ent & RXE_SELF) != 0, s);
+      if (__ballot(ent & RXE_INLINE)) insert((ent & RXE_INLINE) != 0, ent & (RXE_TGT_MASK | RXE_ACCEPT));
+      if (__ballot(ent & RXE_OVF)) {
+        const bool has = (ent & RXE_OVF) != 0;
+        const uint32_t off = ent & RXE_TGT_MASK;
+        const uint32_t cnt = has ? ovf[off] : 0u;
+        for (uint32_t q = 0; __ballot(q < cnt) != 0; q++) {
+          const bool act = q < cnt;
+          insert(act, act ? ovf[off + 1u + q] : 0u);
+        }
+      }
+    }
+
+    if (consume) {
+      // next set too large for the group's list: hand the stream (S_k, k) to the wave kernel
+      const bool spill = alive && n_next > L::CAP;
+      if (__ballot(spill)) {
+        uint32_t slot = 0;
+        if (spill && j == 0) slot = (uint32_t)atomicAdd(p.spill_count, 1ull);
+        slot = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(gshift << 2), (int)slot);  // group leader's slot
+        if (spill) {
+          if (j == 0) {
+            p.spill_streams[slot] = stream;
+            p.spill_k[slot] = k;
+            if (p.anymatch) p.anymatch[(size_t)stream * p.anymatch_stride + (k >> 5)] = am_word;
+          }
+          uint32_t* row = p.spill_rows + (size_t)slot * p.nw64x2;
+          for (uint32_t w = j; w < p.nw64x2; w += G) {  // S_k as a bitmask row, word by word
+            uint32_t v = 0;
+            for (uint32_t q = 0; q < n_cur; q++) {
+              const uint32_t sq = clist[q] & RXE_TGT_MASK;
+              if ((sq >> 5) == w) v |= 1u << (sq & 31u);
+            }
+            row[w] = v;
+          }
+          alive = false;
+        }
+      }
+      wave_sync();
+      // current <- next (FPGA.v:733-737): wipe the filter bits of the entries just listed, swap
+      for (uint32_t it = 0;; it++) {
+        const uint32_t idx = it * G + j;
+        const bool valid = alive && idx < n_next;
+        if (__ballot(valid) == 0) break;
+        if (valid) filt[(nlist[idx] & (32u * L::FW - 1u)) >> 5] = 0u;
+      }
+      tog ^= 1u;
+      n_cur = n_next;
+      wave_sync();
+    }
+    if (p.anymatch && ((k & 31u) == 31u || k + 1 == p.n_passes)) {
+      if (alive && j == 0) p.anymatch[(size_t)stream * p.anymatch_stride + (k >> 5)] = am_word;
+      am_word = 0;
+    }
+  }
+  // final active set: the row was zeroed by the host-side memset; set the listed bits
+  if (p.final_active && alive) {
+    const uint32_t* clist = lists + tog * L::CAP;
+    uint32_t* row = p.final_active + (size_t)stream * p.nw64x2;
+    for (uint32_t idx = j; idx < n_cur; idx += G) {
+      const uint32_t sq = clist[idx] & RXE_TGT_MASK;
+      atomicOr(&row[sq >> 5], 1u << (sq & 31u));
+    }
+  }
+  if (STATS) {
+    if (st_active) atomicAdd(&p.counters[1], st_active);
+    if (st_edges) atomicAdd(&p.counters[2], st_edges);
+  }
+}
+
 }  // namespace
 
 // -------------------------------------------------------------------------------------------------
@@ -363,10 +593,12 @@ __global__ void __launch_bounds__(256) rx_sym_wave_kernel(const RxParams p) {
 int rx_pick_launch(uint32_t kernel, uint32_t size, uint32_t n_streams, int cu_count, size_t lds_per_cu,
                    RxParams* p, RxLaunchCfg* cfg) {
   (void)cu_count;
-  if (kernel == RX_KERNEL_AUTO) kernel = RX_KERNEL_SYM_WAVE;
-  if (kernel != RX_KERNEL_CSR_WAVE && kernel != RX_KERNEL_SYM_WAVE) return RX_EINVAL;
+  if (kernel == RX_KERNEL_AUTO) kernel = RX_KERNEL_SYM_GROUP;
+  if (kernel != RX_KERNEL_CSR_WAVE && kernel != RX_KERNEL_SYM_WAVE && kernel != RX_KERNEL_SYM_GROUP)
+    return RX_EINVAL;
   const uint32_t nw32 = (size + 31u) / 32u;
   p->nw32 = nw32;
+  // wave-per-stream carve (also used by the resume launch that follows a group launch)
   p->lds_words_per_stream = 2u * nw32 + 2u * RX_LIST_CAP;
   const size_t per_wave = (size_t)p->lds_words_per_stream * 4u;
   if (per_wave > lds_per_cu) return RX_ECAPACITY;  // automaton too large for an LDS-resident bitmask
@@ -377,18 +609,31 @@ int rx_pick_launch(uint32_t kernel, uint32_t size, uint32_t n_streams, int cu_co
   cfg->lds_bytes = (uint32_t)(per_wave * wpb);
   uint32_t blocks = (n_streams + wpb - 1) / wpb;
   cfg->grid_blocks = blocks ? blocks : 1;
+  if (kernel == RX_KERNEL_SYM_GROUP && cfg->group_lanes != 4 && cfg->group_lanes != 8 && cfg->group_lanes != 16)
+    cfg->group_lanes = 4;
   return RX_OK;
 }
 
 template <typename K>
-static int launch_one(K kern, const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s) {
-  if (cfg.lds_bytes > 64u * 1024u) {
+static int launch_one(K kern, const RxParams& p, uint32_t grid, uint32_t block, uint32_t lds, hipStream_t s) {
+  if (lds > 64u * 1024u) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds_bytes);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(kern, dim3(cfg.grid_blocks), dim3(cfg.block_threads), cfg.lds_bytes, s, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, p);
   return (int)hipGetLastError();
+}
+
+template <int G>
+static int launch_group(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s) {
+  using L = GroupLayout<G>;
+  const uint32_t wpb = 4;
+  const uint32_t waves = (p.n_streams + L::SPW - 1) / L::SPW;
+  const uint32_t grid = (waves + wpb - 1) / wpb;
+  const uint32_t lds = wpb * L::SPW * L::REGION * 4u;
+  return cfg.stats ? launch_one(rx_sym_group_kernel<G, true>, p, grid ? grid : 1, wpb * 64u, lds, s)
+                   : launch_one(rx_sym_group_kernel<G, false>, p, grid ? grid : 1, wpb * 64u, lds, s);
 }
 
 // returns a hipError_t value (0 = hipSuccess)
@@ -396,11 +641,27 @@ int rx_launch(const RxParams& p, const RxLaunchCfg& cfg, void* hip_stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
   switch (cfg.kernel) {
     case RX_KERNEL_CSR_WAVE:
-      return cfg.stats ? launch_one(rx_csr_wave_kernel<true>, p, cfg, s)
-                       : launch_one(rx_csr_wave_kernel<false>, p, cfg, s);
+      return cfg.stats ? launch_one(rx_csr_wave_kernel<true>, p, cfg.grid_blocks, cfg.block_threads, cfg.lds_bytes, s)
+                       : launch_one(rx_csr_wave_kernel<false>, p, cfg.grid_blocks, cfg.block_threads, cfg.lds_bytes, s);
     case RX_KERNEL_SYM_WAVE:
-      return cfg.stats ? launch_one(rx_sym_wave_kernel<true>, p, cfg, s)
-                       : launch_one(rx_sym_wave_kernel<false>, p, cfg, s);
+      return cfg.stats ? launch_one(rx_sym_wave_kernel<true>, p, cfg.grid_blocks, cfg.block_threads, cfg.lds_bytes, s)
+                       : launch_one(rx_sym_wave_kernel<false>, p, cfg.grid_blocks, cfg.block_threads, cfg.lds_bytes, s);
+    case RX_KERNEL_SYM_GROUP: {
+      int e;
+      if (cfg.group_lanes == 8) e = launch_group<8>(p, cfg, s);
+      else if (cfg.group_lanes == 16) e = launch_group<16>(p, cfg, s);
+      else e = launch_group<4>(p, cfg, s);
+      if (e) return e;
+      // second launch: the wave kernel finishes whatever the group kernel handed off (usually nothing;
+      // the count is read on the device, so no host round-trip)
+      RxParams r = p;
+      r.resume = 1;
+      const uint32_t wpb = cfg.block_threads / 64u;
+      uint32_t grid = (p.n_streams + wpb - 1) / wpb;
+      if (grid > 512u) grid = 512u;
+      return cfg.stats ? launch_one(rx_sym_wave_kernel<true>, r, grid ? grid : 1, cfg.block_threads, cfg.lds_bytes, s)
+                       : launch_one(rx_sym_wave_kernel<false>, r, grid ? grid : 1, cfg.block_threads, cfg.lds_bytes, s);
+    }
     default:
       return (int)hipErrorInvalidValue;
   }

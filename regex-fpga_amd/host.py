@@ -31,7 +31,7 @@ class RxError(RuntimeError):
 class _Opts(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("mode", C.c_uint32), ("kernel", C.c_uint32),
                 ("stream", C.c_void_p), ("k_base", C.c_uint64), ("collect_stats", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("group_lanes", C.c_uint32)]
 
 
 class _Stats(C.Structure):
@@ -205,8 +205,9 @@ def n_passes(stream_len, mode):
     return stream_len + 1
 
 
-def _mk_opts(device, mode, kernel, stream, k_base, collect_stats):
+def _mk_opts(device, mode, kernel, stream, k_base, collect_stats, group_lanes=0):
     o = _Opts()
+    o.group_lanes = group_lanes
     o.struct_size = C.sizeof(_Opts)
     o.device, o.mode, o.kernel = device, mode, kernel
     o.stream = stream
@@ -269,12 +270,12 @@ def _as_rows(data):
 
 def match(nfa, data, mode=MODE_FULL, kernel=KERNEL_AUTO, device=-1, init_active=None, events_cap=1 << 20,
           want_match_count=False, want_total=True, want_anymatch=True, want_final=True, collect_stats=False,
-          k_base=0):
+          k_base=0, group_lanes=0):
     """rx_match(): one-shot match of uint8 [n_streams, stream_len] host rows on one GPU."""
     data, stride = _as_rows(data)
     ns, sl = data.shape
     out = _Out(nfa, ns, sl, mode, events_cap, want_match_count, want_total, want_anymatch, want_final)
-    o = _mk_opts(device, mode, kernel, None, k_base, collect_stats)
+    o = _mk_opts(device, mode, kernel, None, k_base, collect_stats, group_lanes)
     ia = None
     if init_active is not None:
         ia = np.ascontiguousarray(init_active, dtype=np.uint64)
@@ -303,11 +304,11 @@ class Plan:
 
     def __init__(self, nfa, max_streams, max_stream_len, mode=MODE_FULL, kernel=KERNEL_AUTO, device=-1, stream=None,
                  events_cap=1 << 20, want_match_count=False, want_anymatch=True, want_final=True, collect_stats=False,
-                 k_base=0):
+                 k_base=0, group_lanes=0):
         self.nfa, self.mode = nfa, mode
         self.events_cap = events_cap
         self.want = (want_match_count, want_anymatch, want_final)
-        self._o = _mk_opts(device, mode, kernel, stream, k_base, collect_stats)
+        self._o = _mk_opts(device, mode, kernel, stream, k_base, collect_stats, group_lanes)
         self._h = C.c_void_p()
         _chk(lib().rx_plan_create(nfa._h, C.byref(self._o), max_streams, max_stream_len, events_cap,
                                   int(want_match_count), int(want_anymatch), int(want_final), C.byref(self._h)),

@@ -17,7 +17,10 @@ N = 200000
 
 @pytest.fixture(scope="module")
 def kernels(rx):
-    return [rx.KERNEL_CSR_WAVE, rx.KERNEL_SYM_WAVE, rx.KERNEL_AUTO]
+    """Every kernel variant the C-ABI can launch, as rx_opts keyword sets."""
+    return [dict(kernel=rx.KERNEL_CSR_WAVE), dict(kernel=rx.KERNEL_SYM_WAVE),
+            dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=4), dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=8),
+            dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=16), dict(kernel=rx.KERNEL_AUTO)]
 
 
 @pytest.fixture(scope="module")
@@ -54,7 +57,7 @@ def test_kat_ab(rx, orx, kernels):
     for mode in (rx.MODE_FULL, rx.MODE_TB_COMPAT):
         ref = orx.match_batch(W, size, data, mode=mode, want_match_count=True)
         for kern in kernels:
-            got = rx.match(nfa, data, mode=mode, kernel=kern, want_match_count=True, collect_stats=True)
+            got = rx.match(nfa, data, mode=mode, **kern, want_match_count=True, collect_stats=True)
             check_equal(rx, orx, got, ref, ("ab", mode, kern))
     got = rx.match(nfa, data, kernel=rx.KERNEL_AUTO, want_match_count=True)
     assert [(int(e["k"]), int(e["state"])) for e in got["events"]] == [(3, 3), (5, 3)]
@@ -69,7 +72,7 @@ def test_shipped_traces_single_stream(rx, orx, automata, traces, gpu_nfas, kerne
     ref = orx.match_batch(W, size, data, mode=orx.MODE_TB_COMPAT, nthreads=1, want_match_count=True)
     g = G["tb_compat"][key]
     for kern in kernels:
-        got = rx.match(gpu_nfas[name], data, mode=rx.MODE_TB_COMPAT, kernel=kern, want_match_count=True,
+        got = rx.match(gpu_nfas[name], data, mode=rx.MODE_TB_COMPAT, **kern, want_match_count=True,
                        collect_stats=True)
         check_equal(rx, orx, got, ref, (key, kern))
         assert orx.h_match_count(got["match_count"][0]) == g["H_mc"]
@@ -111,7 +114,7 @@ def test_synthetic_batches(rx, orx, automata, traces, gpu_nfas, kernels, workloa
     if workload == "T":
         assert ref["n_events"] > 100
     for kern in kernels:
-        got = rx.match(gpu_nfas["snort_16"], rows, kernel=kern, want_match_count=True, collect_stats=True)
+        got = rx.match(gpu_nfas["snort_16"], rows, **kern, want_match_count=True, collect_stats=True)
         check_equal(rx, orx, got, ref, (workload, kern))
 
 
@@ -125,7 +128,7 @@ def test_ragged_and_edge_shapes(rx, orx, automata, traces, gpu_nfas, kernels):
             for mode in (rx.MODE_FULL, rx.MODE_TB_COMPAT):
                 ref = orx.match_batch(W, size, rows, mode=mode)
                 for kern in kernels:
-                    got = rx.match(gpu_nfas["snort_16"], rows, mode=mode, kernel=kern, collect_stats=True)
+                    got = rx.match(gpu_nfas["snort_16"], rows, mode=mode, **kern, collect_stats=True)
                     check_equal(rx, orx, got, ref, (sl, ns, mode, kern))
     # strided view: rows start at odd addresses (stride 301, offset 1)
     buf = np.zeros(40 * 301 + 8, np.uint8)
@@ -133,7 +136,7 @@ def test_ragged_and_edge_shapes(rx, orx, automata, traces, gpu_nfas, kernels):
     view = np.lib.stride_tricks.as_strided(buf[1:], shape=(40, 298), strides=(301, 1))
     ref = orx.match_batch(W, size, np.ascontiguousarray(view))
     for kern in kernels:
-        got = rx.match(gpu_nfas["snort_16"], view, kernel=kern, collect_stats=True)
+        got = rx.match(gpu_nfas["snort_16"], view, **kern, collect_stats=True)
         check_equal(rx, orx, got, ref, ("strided", kern))
 
 
@@ -150,7 +153,7 @@ def test_device_input_unaligned(rx, orx, automata, traces, gpu_nfas, kernels):
     d = torch.from_numpy(host).cuda()
     ref = orx.match_batch(W, size, rows)
     for kern in kernels:
-        p = rx.Plan(gpu_nfas["snort_16"], ns, sl, kernel=kern, device=0, collect_stats=True)
+        p = rx.Plan(gpu_nfas["snort_16"], ns, sl, **kern, device=0, collect_stats=True)
         p.set_device_input(d.data_ptr() + 1, ns, sl, stride, keepalive=d)
         p.launch()
         p.launch()  # relaunching a resident plan gives the same answer
@@ -169,8 +172,8 @@ def test_chunked_streaming_chain(rx, orx, automata, traces, gpu_nfas, kernels):
     whole = orx.match_batch(W, size, rows)
     cut = 2500
     for kern in kernels:
-        a = rx.match(gpu_nfas["snort_16"], rows[:, :cut], kernel=kern)
-        b = rx.match(gpu_nfas["snort_16"], rows[:, cut:], kernel=kern, init_active=a["final_active"], k_base=cut)
+        a = rx.match(gpu_nfas["snort_16"], rows[:, :cut], **kern)
+        b = rx.match(gpu_nfas["snort_16"], rows[:, cut:], **kern, init_active=a["final_active"], k_base=cut)
         ev_a = a["events"][a["events"]["k"] < cut]
         ev = np.concatenate([ev_a, b["events"]])
         ev = ev[np.lexsort((ev["state"], ev["k"], ev["stream"]))]
@@ -188,7 +191,7 @@ def test_active_set_larger_than_list_capacity(rx, orx, kernels):
     ref = orx.match_batch(W, size, rows, want_match_count=True)
     assert ref["stats"]["sum_active"] > 300 * 20 and ref["n_events"] >= 1
     for kern in kernels:
-        got = rx.match(nfa, rows, kernel=kern, want_match_count=True, collect_stats=True)
+        got = rx.match(nfa, rows, **kern, want_match_count=True, collect_stats=True)
         check_equal(rx, orx, got, ref, ("blowup", kern))
 
 
@@ -205,7 +208,7 @@ def test_random_automata(rx, orx, kernels):
         mode = int(trial & 1)
         ref = orx.match_batch(W, size, rows, mode=mode, want_match_count=True)
         for kern in kernels:
-            got = rx.match(nfa, rows, mode=mode, kernel=kern, want_match_count=True, collect_stats=True)
+            got = rx.match(nfa, rows, mode=mode, **kern, want_match_count=True, collect_stats=True)
             check_equal(rx, orx, got, ref, ("random", trial, kern))
 
 
@@ -228,7 +231,7 @@ def test_full_size_config3_properties(rx, orx, automata, traces, gpu_nfas, kerne
     wl = rx.workloads
     ns, sl = 65536, 1024
     rows = wl.trace_windows(traces[("snort_16", "lo")], traces[("snort_16", "hi")], ns, sl)
-    outs = [rx.match(gpu_nfas["snort_16"], rows, kernel=k, events_cap=1 << 21, collect_stats=True) for k in kernels]
+    outs = [rx.match(gpu_nfas["snort_16"], rows, **k, events_cap=1 << 21, collect_stats=True) for k in kernels]
     a = outs[0]
     for b in outs[1:]:
         for k in ("events", "match_count_total", "anymatch", "final_active"):
