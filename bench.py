@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--workload", choices=["T", "U"], default="T")
     ap.add_argument("--kernel", default="auto", choices=["auto", "csr_wave", "sym_wave", "sym_group"])
     ap.add_argument("--group-lanes", type=int, default=0)
-    ap.add_argument("--cpu-sample-streams", type=int, default=4096)
+    ap.add_argument("--cpu-threads", type=int, default=16, help="cap on oracle threads (box share: 16 per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--all-kernels", action="store_true", help="also time the other kernels (extra keys)")
     return ap.parse_args()
@@ -172,6 +172,7 @@ def main():
     if a.all_kernels:
         extra = {}
         for name, kid, gl in (("csr_wave", rx.KERNEL_CSR_WAVE, 0), ("sym_wave", rx.KERNEL_SYM_WAVE, 0),
+                              ("sym_group1", rx.KERNEL_SYM_GROUP, 1), ("sym_group2", rx.KERNEL_SYM_GROUP, 2),
                               ("sym_group4", rx.KERNEL_SYM_GROUP, 4), ("sym_group8", rx.KERNEL_SYM_GROUP, 8),
                               ("sym_group16", rx.KERNEL_SYM_GROUP, 16)):
             p2 = rx.Plan(nfa, ns, sl, mode=rx.MODE_FULL, kernel=kid, device=local, stream=stream, events_cap=1 << 22,
@@ -188,9 +189,15 @@ def main():
         from oracle import orx  # checker / reported CPU baseline only
         W = orx.load_coe(wl.SNORT_COE)
         size = orx.infer_size(W)
-        nsamp = min(a.cpu_sample_streams, ns)
+        # threads = this process's CPU share (capped), sample sized for ~15 s of CPU work
+        nthr = max(1, min(len(os.sched_getaffinity(0)), a.cpu_threads))
         t = time.perf_counter()
-        ref = orx.match_batch(W, size, rows[:nsamp], mode=orx.MODE_FULL, nthreads=0, want_final=False)
+        orx.match_batch(W, size, rows[:256], mode=orx.MODE_FULL, nthreads=1, want_final=False)
+        per_stream_s = (time.perf_counter() - t) / 256
+        nsamp = int(min(ns, max(nthr * 64, 15.0 / per_stream_s)))
+        t = time.perf_counter()
+        ref = orx.match_batch(W, size, rows[:nsamp], mode=orx.MODE_FULL, nthreads=nthr, want_final=False,
+                              events_cap=1 << 22)
         cpu_s = time.perf_counter() - t
         # cross-check the GPU's algorithmic-byte count and events on the sample
         gev = res["events"]
@@ -198,8 +205,9 @@ def main():
         ok = bool(np.array_equal(gev, ref["events"].astype(gev.dtype)))
         out["cpu_baseline"] = {"value": round(8.0 * nsamp * sl / cpu_s / 1e9, 4), "unit": "Gbit/s",
                                "cores": ref["threads"], "kind": "port",
-                               "sample": f"first {nsamp} streams x {sl} B of the same batch, functional C oracle "
-                                         f"(oracle/rx_oracle.c), {ref['threads']} threads, {cpu_s:.2f} s",
+                               "sample": f"first {nsamp} of {ns} streams x {sl} B of the same batch, functional C "
+                                         f"oracle (oracle/rx_oracle.c), {ref['threads']} threads, {cpu_s:.2f} s wall "
+                                         f"(~{cpu_s * ref['threads']:.0f} core-s)",
                                "events_match_gpu_on_sample": ok}
         # RTL-equivalent baseline: the clock-accurate restatement of FPGA.v + Blk_Mem_tb, 1 core, no skip
         m = 3000

@@ -609,8 +609,10 @@ int rx_pick_launch(uint32_t kernel, uint32_t size, uint32_t n_streams, int cu_co
   cfg->lds_bytes = (uint32_t)(per_wave * wpb);
   uint32_t blocks = (n_streams + wpb - 1) / wpb;
   cfg->grid_blocks = blocks ? blocks : 1;
-  if (kernel == RX_KERNEL_SYM_GROUP && cfg->group_lanes != 4 && cfg->group_lanes != 8 && cfg->group_lanes != 16)
-    cfg->group_lanes = 4;
+  if (kernel == RX_KERNEL_SYM_GROUP) {
+    const uint32_t gl = cfg->group_lanes;
+    if (gl != 1 && gl != 2 && gl != 4 && gl != 8 && gl != 16) cfg->group_lanes = 4;
+  }
   return RX_OK;
 }
 
@@ -628,7 +630,7 @@ static int launch_one(K kern, const RxParams& p, uint32_t grid, uint32_t block, 
 template <int G>
 static int launch_group(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s) {
   using L = GroupLayout<G>;
-  const uint32_t wpb = 4;
+  const uint32_t wpb = (G == 1) ? 2 : 4;
   const uint32_t waves = (p.n_streams + L::SPW - 1) / L::SPW;
   const uint32_t grid = (waves + wpb - 1) / wpb;
   const uint32_t lds = wpb * L::SPW * L::REGION * 4u;
@@ -648,7 +650,9 @@ int rx_launch(const RxParams& p, const RxLaunchCfg& cfg, void* hip_stream) {
                        : launch_one(rx_sym_wave_kernel<false>, p, cfg.grid_blocks, cfg.block_threads, cfg.lds_bytes, s);
     case RX_KERNEL_SYM_GROUP: {
       int e;
-      if (cfg.group_lanes == 8) e = launch_group<8>(p, cfg, s);
+      if (cfg.group_lanes == 1) e = launch_group<1>(p, cfg, s);
+      else if (cfg.group_lanes == 2) e = launch_group<2>(p, cfg, s);
+      else if (cfg.group_lanes == 8) e = launch_group<8>(p, cfg, s);
       else if (cfg.group_lanes == 16) e = launch_group<16>(p, cfg, s);
       else e = launch_group<4>(p, cfg, s);
       if (e) return e;

@@ -19,6 +19,7 @@ N = 200000
 def kernels(rx):
     """Every kernel variant the C-ABI can launch, as rx_opts keyword sets."""
     return [dict(kernel=rx.KERNEL_CSR_WAVE), dict(kernel=rx.KERNEL_SYM_WAVE),
+            dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=1), dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=2),
             dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=4), dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=8),
             dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=16), dict(kernel=rx.KERNEL_AUTO)]
 
