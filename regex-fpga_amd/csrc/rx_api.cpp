@@ -406,6 +406,8 @@ extern "C" int rx_plan_launch(rx_plan* p) {
       HIPCHK(hipMalloc((void**)&p->d_spill_k, p->max_streams * sizeof(uint32_t)));
       HIPCHK(hipMalloc((void**)&p->d_spill_rows, p->max_streams * (size_t)a.nw64x2 * sizeof(uint32_t)));
     }
+    a.pin_state = h.pin_state;
+    a.pin_degree = h.pin_state != 0xFFFFFFFFu ? h.row_ptr()[h.pin_state + 1] - h.row_ptr()[h.pin_state] : 0;
     a.spill_count = p->d_counters + 3;
     a.spill_streams = p->d_spill_streams;
     a.spill_k = p->d_spill_k;

@@ -148,6 +148,24 @@ int rxh_build(const uint32_t* W, size_t nwords, uint32_t size_or_0, RxHostNfa* o
   }
   auto is_acc = [&](uint32_t t) { return (out->accept_bits[t >> 5] >> (t & 31)) & 1u; };
 
+  // ---- pinned state: self-loop on every byte, fed by state 0 on the most bytes -----------------
+  out->pin_state = 0xFFFFFFFFu;
+  {
+    std::vector<uint32_t> fed(size, 0);
+    for (uint32_t j = rp[0]; j < rp[1]; j++) fed[col[j] & 0xFFFFFFu]++;
+    uint32_t best = 0;
+    for (uint32_t i = 1; i < size; i++) {
+      if (fed[i] <= best) continue;
+      bool seen[256] = {false};
+      uint32_t nself = 0;
+      for (uint32_t j = rp[i]; j < rp[i + 1]; j++)
+        if ((col[j] & 0xFFFFFFu) == i && !seen[col[j] >> 24]) { seen[col[j] >> 24] = true; nself++; }
+      if (nself == 256) { best = fed[i]; out->pin_state = i; }
+    }
+  }
+  const uint32_t pin = out->pin_state;
+  auto pin_flag = [&](uint32_t t) { return t == pin ? RXE_PIN : 0u; };
+
   // ---- slice index: for every (state, symbol) the SET of targets its row yields -------------
   out->symidx.assign((size_t)size * 256, 0u);
   out->ovf.assign(1, 0u);
@@ -169,12 +187,12 @@ int rxh_build(const uint32_t* W, size_t nwords, uint32_t size_or_0, RxHostNfa* o
       auto self = std::find(b.begin(), b.end(), i);
       if (self != b.end()) { ent |= RXE_SELF; b.erase(self); }
       if (b.size() == 1) {
-        ent |= RXE_INLINE | b[0] | (is_acc(b[0]) ? RXE_ACCEPT : 0u);
+        ent |= RXE_INLINE | b[0] | (is_acc(b[0]) ? RXE_ACCEPT : 0u) | pin_flag(b[0]);
       } else if (b.size() >= 2) {
         const size_t off = out->ovf.size();
         if (off + b.size() + 1 > RXE_TGT_MASK) return RX_ECAPACITY;
         out->ovf.push_back((uint32_t)b.size());
-        for (uint32_t t : b) out->ovf.push_back(t | (is_acc(t) ? RXE_ACCEPT : 0u));
+        for (uint32_t t : b) out->ovf.push_back(t | (is_acc(t) ? RXE_ACCEPT : 0u) | pin_flag(t));
         ent |= RXE_OVF | (uint32_t)off;
       }
       out->symidx[(size_t)i * 256 + c] = ent;

@@ -20,6 +20,7 @@ static constexpr uint32_t RXE_INLINE = 0x80000000u;
 static constexpr uint32_t RXE_ACCEPT = 0x40000000u;
 static constexpr uint32_t RXE_SELF = 0x20000000u;
 static constexpr uint32_t RXE_OVF = 0x10000000u;
+static constexpr uint32_t RXE_PIN = 0x08000000u;   // target is the pinned state (see RxHostNfa::pin_state)
 static constexpr uint32_t RXE_TGT_MASK = 0x00FFFFFFu;
 
 // Active-list entry (LDS): state id in bits 23:0, RXE_ACCEPT if the state is an accept state.
@@ -64,9 +65,11 @@ struct RxParams {
   uint32_t* spill_k;                // [n_streams] pass at which the stream must be resumed
   uint32_t* spill_rows;             // [n_streams][nw64x2] S_k of the spilled stream as a bitmask row
   uint32_t resume;                  // wave kernel: 1 = walk the spill list instead of all streams
+  uint32_t pin_state;               // group kernel: pinned state id, 0xFFFFFFFF = none
+  uint32_t pin_degree;              // its row length (for the algorithmic-byte statistics)
 };
 
-static constexpr uint32_t RX_GROUP_CAP = 32;     // group kernel: active-list capacity per stream
+static constexpr uint32_t RX_GROUP_CAP = 24;     // group kernel: active-list capacity per stream
 static constexpr uint32_t RX_GROUP_FILTER_WORDS = 32;  // 1024-bit hashed dedup filter per stream
 
 struct RxLaunchCfg {
@@ -91,6 +94,9 @@ struct RxHostNfa {
   std::vector<uint32_t> symidx;       // size*256
   std::vector<uint32_t> ovf;          // ovf[0] unused so that offset 0 never occurs
   std::vector<uint32_t> accept_bits;  // ceil(size/32)
+  // A state with a self-loop on all 256 bytes stays active forever once entered.  The one state 0 feeds on
+  // the most bytes (snort_16: state 1, the `.*` state) is "pinned": targets equal to it carry RXE_PIN.
+  uint32_t pin_state = 0xFFFFFFFFu;
   const uint32_t* row_ptr() const { return words.data(); }
   const uint32_t* col() const { return words.data() + size + 1; }
 };

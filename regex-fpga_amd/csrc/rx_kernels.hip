@@ -381,6 +381,13 @@ __global__ void __launch_bounds__(256) rx_sym_wave_kernel(const RxParams p) {
 //   * __ballot + popcount of the group's nibble for list slots;
 //   * bit already set (true duplicate or hash collision) => that lane scans the group's next list
 //     (rare; one lane per group at a time so two equal targets cannot both be appended).
+// Two filters alternate by pass: the entries of the current list were inserted through filter P, so
+// the lane that processes an entry zeroes its word in P (no separate clearing sweep) while new
+// targets go through filter Q.
+// The "pinned" state (a state with a self-loop on all 256 bytes that state 0 reaches on every byte —
+// the `.*` state 1 of snort_16) never leaves a stream once active, so it is kept as one flag per
+// stream instead of a list entry; its slice row sits in LDS (1 KB per block) and its out-edges are
+// taken by the otherwise idle lane 0 of the group.
 // A stream whose next set would exceed RX_GROUP_CAP is handed to the wavefront-per-stream kernel in
 // resume mode (S_k as a bitmask row + k), so results stay exact for any automaton / input.
 template <int G>
@@ -388,34 +395,43 @@ struct GroupLayout {
   static constexpr uint32_t FW = RX_GROUP_FILTER_WORDS;
   static constexpr uint32_t CAP = RX_GROUP_CAP;
   static constexpr uint32_t BUFW = 4u * G;  // byte window: 16 B per lane
-  static constexpr uint32_t RAW = FW + 2u * CAP + BUFW;
+  static constexpr uint32_t RAW = 2u * FW + 2u * CAP + BUFW;
   // region stride == G (mod 2G): within a 32-lane half the groups' list slots (g*REGION + j) fall on
   // distinct LDS banks, and equal filter words of different streams are at most 2-way conflicted
   static constexpr uint32_t PAD = ((G + 2u * G * 64u) - RAW) % (2u * G);
   static constexpr uint32_t REGION = RAW + PAD;
   static constexpr uint32_t SPW = 64u / G;  // streams per wavefront
+  static constexpr uint32_t PINW = 256u;    // pinned state's slice row, shared by the block
 };
 
 template <int G, bool STATS>
 __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
   using L = GroupLayout<G>;
-  constexpr uint32_t GMASK = (G == 32) ? 0xFFFFFFFFu : ((1u << G) - 1u);
+  constexpr uint32_t GMASK = (1u << G) - 1u;
   constexpr uint32_t CH = 16u * G;  // bytes of each stream held in LDS at a time
+  constexpr uint32_t HMASK = 32u * L::FW - 1u;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wib = threadIdx.x >> 6, wpb = blockDim.x >> 6;
   const uint32_t g = lane / G, j = lane % G;
   const uint32_t gshift = lane & ~(uint32_t)(G - 1);
   const uint32_t below = (1u << j) - 1u;
-  uint32_t* reg = lds + ((size_t)wib * L::SPW + g) * L::REGION;
-  uint32_t* filt = reg;
-  uint32_t* lists = reg + L::FW;                 // [2][CAP]
+  uint32_t* pinrow = lds;
+  uint32_t* reg = lds + L::PINW + ((size_t)wib * L::SPW + g) * L::REGION;
+  uint32_t* filts = reg;                         // [2][FW]
+  uint32_t* lists = reg + 2u * L::FW;            // [2][CAP]
   uint32_t* bufw = lists + 2u * L::CAP;          // [BUFW] byte window
-  const uint8_t* buf8 = reinterpret_cast<const uint8_t*>(bufw);
   const uint32_t* __restrict__ rp = p.words;
   const uint32_t* __restrict__ symidx = p.symidx;
   const uint32_t* __restrict__ ovf = p.ovf;
   unsigned long long st_active = 0, st_edges = 0;
+
+  // pinned state's row -> LDS (self-loop flag stripped: survival is the per-stream flag)
+  const bool have_pin = p.pin_state != 0xFFFFFFFFu;
+  if (have_pin)
+    for (uint32_t w = threadIdx.x; w < 256u; w += blockDim.x)
+      pinrow[w] = symidx[(size_t)p.pin_state * 256u + w] & ~RXE_SELF;
+  __syncthreads();  // the only block-wide barrier; after this the waves never meet again
 
   const uint32_t wave = blockIdx.x * wpb + wib;
   const uint32_t stream = wave * L::SPW + g;
@@ -440,9 +456,10 @@ __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
     }
   };
 
-  for (uint32_t w = j; w < L::FW; w += G) filt[w] = 0u;
+  for (uint32_t w = j; w < 2u * L::FW; w += G) filts[w] = 0u;
   if (j == 0) lists[0] = p.state0_entry;  // FPGA.v:134-147: current = {state 0}
-  uint32_t n_cur = 1, n_next = 0, tog = 0, am_word = 0;
+  uint32_t n_cur = 1, n_next = 0, tog = 0, am_word = 0, cw = 0;
+  uint32_t pinned = 0;                    // 1 once the pinned state is active in this group's stream
   uint32_t nxt[4];
   load16(0, nxt);
   wave_sync();
@@ -451,79 +468,180 @@ __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
     const bool consume = k < p.n_consume;
     uint32_t c = 0;
     if (consume) {
-      if ((k % CH) == 0) {  // refill the LDS byte window, fetch the next one into registers
-        wave_sync();
+      if ((k & 3u) == 0) {
+        if ((k % CH) == 0) {  // refill the LDS byte window, fetch the next one into registers
+          wave_sync();
 #pragma unroll
-        for (int q = 0; q < 4; q++) bufw[j * 4u + q] = nxt[q];
-        load16(k / CH + 1u, nxt);
-        wave_sync();
+          for (int q = 0; q < 4; q++) bufw[j * 4u + q] = nxt[q];
+          load16(k / CH + 1u, nxt);
+          wave_sync();
+        }
+        cw = bufw[(k % CH) >> 2];  // 4 input bytes of this group's stream (same address in all G lanes)
       }
-      c = buf8[k % CH];  // input_char of this group's stream (same address in all G lanes: broadcast)
+      c = (cw >> ((k & 3u) * 8u)) & 0xFFu;  // input_char
     }
     uint32_t* clist = lists + tog * L::CAP;
     uint32_t* nlist = lists + (tog ^ 1u) * L::CAP;
+    uint32_t* fcur = filts + tog * L::FW;          // filter the current entries went through
+    uint32_t* fnext = filts + (tog ^ 1u) * L::FW;  // filter for this pass's insertions (all zero)
     n_next = 0;
+    uint32_t pin_next = pinned;
 
-    // insert target entry t into this group's next set; wave-uniform call
+    const uint32_t gbelow = below;
+    auto grp_bits = [&](uint64_t m) { return (uint32_t)(m >> gshift) & GMASK; };
+    // accept pulses of up to one entry per lane; wave-uniform call
+    auto pulses = [&](bool acc, uint32_t s) {
+      const uint64_t ma = __ballot(acc);
+      if (ma) {
+        uint32_t dummy = 0;
+        emit_events(p, acc, s, stream, k, lane, dummy);
+        if (grp_bits(ma)) am_word |= 1u << (k & 31u);
+      }
+    };
+    // exact membership check for candidates whose filter bit was already set (true duplicate or hash
+    // collision): one lane per group at a time scans the group's next list; wave-uniform call
+    auto resolve = [&](bool maybe, uint32_t t) {
+      uint32_t gm = grp_bits(__ballot(maybe));
+      while (__ballot(gm != 0)) {
+        const bool mine = maybe && gm != 0 && (gm & (0u - gm)) == (1u << j);
+        bool found = false;
+        if (mine) {
+          const uint32_t lim = n_next < L::CAP ? n_next : L::CAP;
+          for (uint32_t q = 0; q < lim; q++) found |= ((nlist[q] ^ t) & RXE_TGT_MASK) == 0;
+        }
+        const bool app = mine && !found;
+        const uint32_t ga = grp_bits(__ballot(app));
+        if (app && n_next < L::CAP) nlist[n_next] = t & (RXE_TGT_MASK | RXE_ACCEPT);
+        n_next += ga ? 1u : 0u;
+        gm &= gm - 1u;
+        wave_sync();
+      }
+    };
+    // insert one candidate per lane into the group's next set; wave-uniform call (slow paths)
     auto insert = [&](bool pred, uint32_t t) {
-      const uint32_t h = t & (32u * L::FW - 1u);
+      const bool topin = pred && (t & RXE_PIN) != 0;  // the pinned state is a flag, not a list entry
+      if (grp_bits(__ballot(topin))) pin_next = 1;
+      pred = pred && !topin;
+      const uint32_t h = t & HMASK;
       const uint32_t bit = 1u << (h & 31u);
       uint32_t old = 0;
-      if (pred) old = atomicOr(&filt[h >> 5], bit);
+      if (pred) old = atomicOr(&fnext[h >> 5], bit);
       const bool fresh = pred && (old & bit) == 0;
       const bool maybe = pred && (old & bit) != 0;
-      const uint32_t gb = (uint32_t)(__ballot(fresh) >> gshift) & GMASK;
-      const uint32_t slot = n_next + (uint32_t)__popc(gb & below);
-      if (fresh && slot < L::CAP) nlist[slot] = t;
+      const uint32_t gb = grp_bits(__ballot(fresh));
+      const uint32_t slot = n_next + (uint32_t)__popc(gb & gbelow);
+      if (fresh && slot < L::CAP) nlist[slot] = t & (RXE_TGT_MASK | RXE_ACCEPT);
       n_next += (uint32_t)__popc(gb);
-      const uint64_t mm = __ballot(maybe);
-      if (mm) {  // rare: true duplicate or filter collision -> exact check against the list
-        uint32_t gm = (uint32_t)(mm >> gshift) & GMASK;
+      if (__ballot(maybe)) {
         wave_sync();
-        while (__ballot(gm != 0)) {
-          const bool mine = maybe && gm != 0 && (gm & (0u - gm)) == (1u << j);
-          bool found = false;
-          if (mine) {
-            const uint32_t lim = n_next < L::CAP ? n_next : L::CAP;
-            for (uint32_t q = 0; q < lim; q++) found |= ((nlist[q] ^ t) & RXE_TGT_MASK) == 0;
-          }
-          const bool app = mine && !found;
-          const uint32_t ga = (uint32_t)(__ballot(app) >> gshift) & GMASK;
-          if (app && n_next < L::CAP) nlist[n_next] = t;
-          n_next += ga ? 1u : 0u;
-          gm &= gm - 1u;
-          wave_sync();
-        }
+        resolve(maybe, t);
+      }
+    };
+    auto insert_ovf = [&](uint32_t ent) {
+      const bool has = (ent & RXE_OVF) != 0;
+      const uint32_t off = ent & RXE_TGT_MASK;
+      const uint32_t cnt = has ? ovf[off] : 0u;
+      for (uint32_t q = 0; __ballot(q < cnt) != 0; q++) {
+        const bool act = q < cnt;
+        insert(act, act ? ovf[off + 1u + q] : 0u);
       }
     };
 
-    for (uint32_t it = 0;; it++) {
-      const uint32_t idx = it * G + j;
-      const bool valid = alive && idx < n_cur;
-      if (__ballot(valid) == 0) break;
-      const uint32_t e = valid ? clist[idx] : 0u;
-      const uint32_t s = e & RXE_TGT_MASK;
-      const bool acc = valid && (e & RXE_ACCEPT);
-      {  // accept pulses
-        const uint64_t ma = __ballot(acc);
-        if (ma) {
-          uint32_t dummy = 0;
-          emit_events(p, acc, s, stream, k, lane, dummy);
-          if ((uint32_t)(ma >> gshift) & GMASK) am_word |= 1u << (k & 31u);
-        }
+    if (!consume) {  // last pass of full mode: accept check only
+      for (uint32_t it = 0;; it++) {
+        const uint32_t idx = it * G + j;
+        const bool valid = alive && idx < n_cur;
+        if (__ballot(valid) == 0) break;
+        const uint32_t e = valid ? clist[idx] : 0u;
+        pulses(valid && (e & RXE_ACCEPT), e & RXE_TGT_MASK);
       }
-      if (!consume) continue;
-      if (STATS && valid) { st_active += 1; st_edges += rp[s + 1] - rp[s]; }
-      const uint32_t ent = (valid && !acc) ? symidx[(size_t)s * 256u + c] : 0u;
-      if (__ballot(ent & RXE_SELF)) insert((ent & RXE_SELF) != 0, s);
-      if (__ballot(ent & RXE_INLINE)) insert((ent & RXE_INLINE) != 0, ent & (RXE_TGT_MASK | RXE_ACCEPT));
-      if (__ballot(ent & RXE_OVF)) {
-        const bool has = (ent & RXE_OVF) != 0;
-        const uint32_t off = ent & RXE_TGT_MASK;
-        const uint32_t cnt = has ? ovf[off] : 0u;
-        for (uint32_t q = 0; __ballot(q < cnt) != 0; q++) {
-          const bool act = q < cnt;
-          insert(act, act ? ovf[off + 1u + q] : 0u);
+    } else {
+      // ---- batched fast path: virtual entries 0 .. 2G-1 of every stream, two per lane ----------
+      // virtual entry 0 of a pinned stream is the pinned state (lane 0); list entries follow.
+      // Phase A: both list reads in flight.
+      const bool is_pin = alive && pinned && j == 0;
+      const uint32_t i0 = j - pinned, i1 = G + j - pinned;
+      const bool v0 = alive && j >= pinned && i0 < n_cur;
+      const bool v1 = alive && i1 < n_cur;
+      uint32_t e0 = 0, e1 = 0;
+      if (v0) e0 = clist[i0];
+      if (v1) e1 = clist[i1];
+      const uint32_t s0 = e0 & RXE_TGT_MASK, s1 = e1 & RXE_TGT_MASK;
+      const bool a0 = v0 && (e0 & RXE_ACCEPT), a1 = v1 && (e1 & RXE_ACCEPT);
+      if (__ballot(a0 || a1)) { pulses(a0, s0); pulses(a1, s1); }
+      // these entries went through filter fcur: zero their words for the pass after next
+      if (v0) fcur[(s0 & HMASK) >> 5] = 0u;
+      if (v1) fcur[(s1 & HMASK) >> 5] = 0u;
+      // Phase B: both slice dwords in flight (the current byte's slice of rows s0, s1)
+      uint32_t x0 = 0, x1 = 0;
+      if (v0 && !a0) x0 = symidx[(size_t)s0 * 256u + c];
+      if (v1 && !a1) x1 = symidx[(size_t)s1 * 256u + c];
+      if (is_pin) x0 = pinrow[c];
+      if (STATS) {
+        if (v0) { st_active += 1; st_edges += rp[s0 + 1] - rp[s0]; }
+        if (v1) { st_active += 1; st_edges += rp[s1 + 1] - rp[s1]; }
+        if (is_pin) { st_active += 1; st_edges += p.pin_degree; }
+      }
+      // Phase C: four candidates per lane: self0, inline0, self1, inline1
+      bool p0 = (x0 & RXE_SELF) != 0, p1 = (x0 & RXE_INLINE) != 0;
+      bool p2 = (x1 & RXE_SELF) != 0, p3 = (x1 & RXE_INLINE) != 0;
+      {
+        const bool tp1 = p1 && (x0 & RXE_PIN), tp3 = p3 && (x1 & RXE_PIN);
+        if (grp_bits(__ballot(tp1 || tp3))) pin_next = 1;
+        p1 = p1 && !tp1;
+        p3 = p3 && !tp3;
+      }
+      const uint32_t h0 = e0 & HMASK, h1 = x0 & HMASK, h2 = e1 & HMASK, h3 = x1 & HMASK;
+      const uint32_t b0 = 1u << (h0 & 31u), b1 = 1u << (h1 & 31u), b2 = 1u << (h2 & 31u), b3 = 1u << (h3 & 31u);
+      uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+      if (p0) o0 = atomicOr(&fnext[h0 >> 5], b0);  // four ds_or_rtn_b32 back to back, one wait
+      if (p1) o1 = atomicOr(&fnext[h1 >> 5], b1);
+      if (p2) o2 = atomicOr(&fnext[h2 >> 5], b2);
+      if (p3) o3 = atomicOr(&fnext[h3 >> 5], b3);
+      // Phase D: slots by ballot + popcount of the group's bits
+      const bool f0 = p0 && !(o0 & b0), f1 = p1 && !(o1 & b1), f2 = p2 && !(o2 & b2), f3 = p3 && !(o3 & b3);
+      const bool m0 = p0 && (o0 & b0), m1 = p1 && (o1 & b1), m2 = p2 && (o2 & b2), m3 = p3 && (o3 & b3);
+      const uint32_t g0 = grp_bits(__ballot(f0)), g1 = grp_bits(__ballot(f1));
+      const uint32_t g2 = grp_bits(__ballot(f2)), g3 = grp_bits(__ballot(f3));
+      uint32_t slot = n_next + (uint32_t)__popc(g0 & gbelow);
+      if (f0 && slot < L::CAP) nlist[slot] = e0 & (RXE_TGT_MASK | RXE_ACCEPT);
+      n_next += (uint32_t)__popc(g0);
+      slot = n_next + (uint32_t)__popc(g1 & gbelow);
+      if (f1 && slot < L::CAP) nlist[slot] = x0 & (RXE_TGT_MASK | RXE_ACCEPT);
+      n_next += (uint32_t)__popc(g1);
+      slot = n_next + (uint32_t)__popc(g2 & gbelow);
+      if (f2 && slot < L::CAP) nlist[slot] = e1 & (RXE_TGT_MASK | RXE_ACCEPT);
+      n_next += (uint32_t)__popc(g2);
+      slot = n_next + (uint32_t)__popc(g3 & gbelow);
+      if (f3 && slot < L::CAP) nlist[slot] = x1 & (RXE_TGT_MASK | RXE_ACCEPT);
+      n_next += (uint32_t)__popc(g3);
+      if (__ballot(m0 || m1 || m2 || m3)) {  // rare
+        wave_sync();
+        resolve(m0, e0);
+        resolve(m1, x0);
+        resolve(m2, e1);
+        resolve(m3, x1);
+      }
+      if (__ballot((x0 | x1) & RXE_OVF)) {  // rows with several targets on this byte
+        insert_ovf(x0);
+        insert_ovf(x1);
+      }
+      // ---- streams with more than 2G virtual entries: one entry per lane per iteration ----------
+      if (__ballot(alive && n_cur + pinned > 2u * G)) {
+        for (uint32_t it = 2;; it++) {
+          const uint32_t idx = it * G + j - pinned;
+          const bool valid = alive && idx < n_cur;
+          if (__ballot(valid) == 0) break;
+          const uint32_t e = valid ? clist[idx] : 0u;
+          const uint32_t s = e & RXE_TGT_MASK;
+          const bool acc = valid && (e & RXE_ACCEPT);
+          pulses(acc, s);
+          if (valid) fcur[(s & HMASK) >> 5] = 0u;
+          if (STATS && valid) { st_active += 1; st_edges += rp[s + 1] - rp[s]; }
+          const uint32_t ent = (valid && !acc) ? symidx[(size_t)s * 256u + c] : 0u;
+          insert((ent & RXE_SELF) != 0, e);
+          insert((ent & RXE_INLINE) != 0, ent);
+          if (__ballot(ent & RXE_OVF)) insert_ovf(ent);
         }
       }
     }
@@ -543,26 +661,21 @@ __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
           }
           uint32_t* row = p.spill_rows + (size_t)slot * p.nw64x2;
           for (uint32_t w = j; w < p.nw64x2; w += G) {  // S_k as a bitmask row, word by word
-            uint32_t v = 0;
+            uint32_t vv = 0;
             for (uint32_t q = 0; q < n_cur; q++) {
               const uint32_t sq = clist[q] & RXE_TGT_MASK;
-              if ((sq >> 5) == w) v |= 1u << (sq & 31u);
+              if ((sq >> 5) == w) vv |= 1u << (sq & 31u);
             }
-            row[w] = v;
+            if (pinned && (p.pin_state >> 5) == w) vv |= 1u << (p.pin_state & 31u);
+            row[w] = vv;
           }
           alive = false;
         }
       }
-      wave_sync();
-      // current <- next (FPGA.v:733-737): wipe the filter bits of the entries just listed, swap
-      for (uint32_t it = 0;; it++) {
-        const uint32_t idx = it * G + j;
-        const bool valid = alive && idx < n_next;
-        if (__ballot(valid) == 0) break;
-        if (valid) filt[(nlist[idx] & (32u * L::FW - 1u)) >> 5] = 0u;
-      }
+      // current <- next (FPGA.v:733-737)
       tog ^= 1u;
       n_cur = n_next;
+      pinned = pin_next;
       wave_sync();
     }
     if (p.anymatch && ((k & 31u) == 31u || k + 1 == p.n_passes)) {
@@ -578,6 +691,7 @@ __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
       const uint32_t sq = clist[idx] & RXE_TGT_MASK;
       atomicOr(&row[sq >> 5], 1u << (sq & 31u));
     }
+    if (pinned && j == 0) atomicOr(&row[p.pin_state >> 5], 1u << (p.pin_state & 31u));
   }
   if (STATS) {
     if (st_active) atomicAdd(&p.counters[1], st_active);
@@ -633,7 +747,7 @@ static int launch_group(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s
   const uint32_t wpb = (G == 1) ? 2 : 4;
   const uint32_t waves = (p.n_streams + L::SPW - 1) / L::SPW;
   const uint32_t grid = (waves + wpb - 1) / wpb;
-  const uint32_t lds = wpb * L::SPW * L::REGION * 4u;
+  const uint32_t lds = (L::PINW + wpb * L::SPW * L::REGION) * 4u;
   return cfg.stats ? launch_one(rx_sym_group_kernel<G, true>, p, grid ? grid : 1, wpb * 64u, lds, s)
                    : launch_one(rx_sym_group_kernel<G, false>, p, grid ? grid : 1, wpb * 64u, lds, s);
 }
