@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--streams-per-gpu", type=int, default=65536)
     ap.add_argument("--stream-len", type=int, default=1024)
     ap.add_argument("--workload", choices=["T", "U"], default="T")
-    ap.add_argument("--kernel", default="auto", choices=["auto", "csr_wave", "sym_wave", "sym_group"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "csr_wave", "sym_wave", "sym_group", "sym_pack"])
     ap.add_argument("--group-lanes", type=int, default=0)
     ap.add_argument("--cpu-threads", type=int, default=16, help="cap on oracle threads (box share: 16 per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -86,7 +86,7 @@ def main():
 
     wl = rx.workloads
     kern = {"auto": rx.KERNEL_AUTO, "csr_wave": rx.KERNEL_CSR_WAVE, "sym_wave": rx.KERNEL_SYM_WAVE,
-            "sym_group": rx.KERNEL_SYM_GROUP}[a.kernel]
+            "sym_group": rx.KERNEL_SYM_GROUP, "sym_pack": rx.KERNEL_SYM_PACK}[a.kernel]
     nfa = rx.Nfa.load_coe(wl.SNORT_COE)
     traces = (rx.load_mem(wl.TRACES[("snort_16", "lo")]), rx.load_mem(wl.TRACES[("snort_16", "hi")]))
     ns, sl = a.streams_per_gpu, a.stream_len
@@ -174,7 +174,8 @@ def main():
         for name, kid, gl in (("csr_wave", rx.KERNEL_CSR_WAVE, 0), ("sym_wave", rx.KERNEL_SYM_WAVE, 0),
                               ("sym_group1", rx.KERNEL_SYM_GROUP, 1), ("sym_group2", rx.KERNEL_SYM_GROUP, 2),
                               ("sym_group4", rx.KERNEL_SYM_GROUP, 4), ("sym_group8", rx.KERNEL_SYM_GROUP, 8),
-                              ("sym_group16", rx.KERNEL_SYM_GROUP, 16)):
+                              ("sym_group16", rx.KERNEL_SYM_GROUP, 16), ("sym_pack16", rx.KERNEL_SYM_PACK, 16),
+                              ("sym_pack24", rx.KERNEL_SYM_PACK, 24), ("sym_pack32", rx.KERNEL_SYM_PACK, 32)):
             p2 = rx.Plan(nfa, ns, sl, mode=rx.MODE_FULL, kernel=kid, device=local, stream=stream, events_cap=1 << 22,
                          group_lanes=gl)
             p2.set_device_input(d_rows.data_ptr(), ns, sl, sl, keepalive=d_rows)

@@ -100,6 +100,10 @@ enum {
   RX_KERNEL_SYM_GROUP = 3 /* G lanes per stream (64/G streams per wavefront), slice index;
                              streams whose active set outgrows the group's list are finished by
                              RX_KERNEL_SYM_WAVE in the same call                            */
+  ,
+  RX_KERNEL_SYM_PACK = 4  /* S streams per wavefront, lanes assigned dynamically to one wave-wide
+                             list of (stream,state) entries; rx_opts.group_lanes = S (8/16/24/32);
+                             same hand-off to RX_KERNEL_SYM_WAVE                             */
 };
 
 typedef struct rx_opts {

@@ -395,12 +395,14 @@ extern "C" int rx_plan_launch(rx_plan* p) {
   a.final_active = p->want_final ? p->d_final : nullptr;
   uint32_t kernel = p->opts.kernel;
   // a caller-supplied start set is a bitmask row: that is the wave kernel's dense form
-  if (p->have_init && (kernel == RX_KERNEL_AUTO || kernel == RX_KERNEL_SYM_GROUP)) kernel = RX_KERNEL_SYM_WAVE;
+  if (p->have_init && (kernel == RX_KERNEL_AUTO || kernel == RX_KERNEL_SYM_GROUP || kernel == RX_KERNEL_SYM_PACK))
+    kernel = RX_KERNEL_SYM_WAVE;
   p->cfg.group_lanes = p->opts.group_lanes;
   rc = rx_pick_launch(kernel, h.size, a.n_streams, p->tab.cu_count, p->tab.lds_per_cu, &a, &p->cfg);
   if (rc) return rc;
   p->cfg.stats = p->opts.collect_stats != 0;
-  if (p->cfg.kernel == RX_KERNEL_SYM_GROUP) {
+  const bool two_tier = p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK;
+  if (two_tier) {
     if (!p->d_spill_rows) {  // hand-off area group kernel -> wave kernel, sized so that it cannot overflow
       HIPCHK(hipMalloc((void**)&p->d_spill_streams, p->max_streams * sizeof(uint32_t)));
       HIPCHK(hipMalloc((void**)&p->d_spill_k, p->max_streams * sizeof(uint32_t)));
@@ -426,7 +428,7 @@ extern "C" int rx_plan_launch(rx_plan* p) {
   }
   auto& ev = p->evs[p->n_timed];
   HIPCHK(hipEventRecord(ev.first, p->stream));  // brackets the match kernel(s) only, on their own stream
-  if (p->cfg.kernel == RX_KERNEL_SYM_GROUP && p->want_final)  // the group kernel ORs bits into zeroed rows
+  if (two_tier && p->want_final)  // the group / pack kernels OR bits into zeroed rows
     HIPCHK(hipMemsetAsync(p->d_final, 0, p->n_streams * (size_t)a.nw64x2 * sizeof(uint32_t), p->stream));
   hipError_t e = (hipError_t)rx_launch(a, p->cfg, p->stream);
   if (e != hipSuccess) return hip_fail(e, "kernel launch");
@@ -492,7 +494,7 @@ extern "C" int rx_plan_download(rx_plan* p, rx_result* res) {
   st.n_events = cnt[0];
   st.kernel_ms = p->last_ms;
   st.kernel_used = p->cfg.kernel;
-  st.n_launches = p->cfg.kernel == RX_KERNEL_SYM_GROUP ? 2 : 1;
+  st.n_launches = (p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK) ? 2 : 1;
   if (p->cfg.stats) {
     st.sum_active = cnt[1];
     st.sum_edges = cnt[2];

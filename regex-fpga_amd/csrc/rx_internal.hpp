@@ -70,6 +70,7 @@ struct RxParams {
 };
 
 static constexpr uint32_t RX_GROUP_CAP = 24;     // group kernel: active-list capacity per stream
+static constexpr uint32_t RX_PACK_CAP = 192;      // pack kernel: wave-wide active-list capacity (entries)
 static constexpr uint32_t RX_GROUP_FILTER_WORDS = 32;  // 1024-bit hashed dedup filter per stream
 
 struct RxLaunchCfg {

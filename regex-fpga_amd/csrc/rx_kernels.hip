@@ -26,6 +26,9 @@
 // the next pass walks the bitmask instead ("dense" form).  Results are identical either way.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "rx_internal.hpp"
 
 namespace {
@@ -699,6 +702,243 @@ __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
   }
 }
 
+// =================================================================================================
+// Kernel 4: S streams per wavefront, lanes assigned DYNAMICALLY to (stream, state) entries
+// =================================================================================================
+// Static G-lane groups still idle most lanes (|S_k| is 1-3 but the wave pays for the largest group).
+// Here a wavefront owns S streams and ONE wave-wide active list whose entries carry the stream slot
+// (bits 28:24) next to the state id: lane L simply takes entry L, whatever stream it belongs to, so a
+// pass is one sweep of ceil(N/64) iterations with N = sum of the S active-set sizes (about 2.3 S).
+//   * per stream in LDS: two alternating 1024-bit hashed filters (insert through one, the entries
+//     that went through the other zero their word when processed), a 16-byte input window, one word
+//     of any-match bits;
+//   * slots of the wave-wide next list come from __ballot + mbcnt (wave-level, scalar count);
+//   * filter bit already set => wave-parallel exact scan of the next list for that (stream,state);
+//   * lanes 0..S-1 additionally own one stream each for input refill and bitmap stores;
+//   * next list would exceed RX_PACK_CAP => all S streams are handed to the wave kernel (resume).
+template <int S>
+struct PackLayout {
+  static constexpr uint32_t FW = RX_GROUP_FILTER_WORDS;
+  static constexpr uint32_t CAPW = RX_PACK_CAP;
+  static constexpr uint32_t WINW = 4;                       // 16 input bytes per stream
+  static constexpr uint32_t STRIDE = 2u * FW + WINW + 1u;   // + any-match word; odd => banks spread
+  static constexpr uint32_t WAVE_WORDS = 2u * CAPW + S * STRIDE + S;  // lists, stream regions, spill slots
+};
+
+template <int S, bool STATS>
+__global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
+  using L = PackLayout<S>;
+  constexpr uint32_t HMASK = 32u * L::FW - 1u;
+  constexpr uint32_t SID_SHIFT = 24, SID_MASK = 31u << SID_SHIFT;
+  constexpr uint32_t KEY_MASK = RXE_TGT_MASK | SID_MASK;
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wib = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  uint32_t* wl = lds + (size_t)wib * L::WAVE_WORDS;  // [2][CAPW] wave-wide lists
+  uint32_t* sreg0 = wl + 2u * L::CAPW;               // [S][STRIDE]: filters[2][FW], window[WINW], am word
+  uint32_t* slotw = sreg0 + S * L::STRIDE;           // [S] spill slots
+  const uint32_t* __restrict__ rp = p.words;
+  const uint32_t* __restrict__ symidx = p.symidx;
+  const uint32_t* __restrict__ ovf = p.ovf;
+  unsigned long long st_active = 0, st_edges = 0;
+
+  const uint32_t wave = blockIdx.x * wpb + wib;
+  const uint32_t stream0 = wave * S;
+  if (stream0 >= p.n_streams) return;
+  const uint32_t n_mine = p.n_streams - stream0 < (uint32_t)S ? p.n_streams - stream0 : (uint32_t)S;
+  const bool owner = lane < n_mine;  // lane == stream slot it owns
+  const uint8_t* base = p.bytes + (size_t)(stream0 + (owner ? lane : 0)) * p.stride;
+  const bool aligned = (reinterpret_cast<uintptr_t>(base) & 3u) == 0;
+  auto load16 = [&](uint32_t chunk, uint32_t (&w)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint32_t o = chunk * 16u + 4u * q;
+      uint32_t v = 0;
+      if (owner) {
+        if (aligned && o + 4u <= p.stream_len) v = *reinterpret_cast<const uint32_t*>(base + o);
+        else
+          for (uint32_t b = 0; b < 4; b++)
+            if (o + b < p.stream_len) v |= (uint32_t)base[o + b] << (8u * b);
+      }
+      w[q] = v;
+    }
+  };
+
+  for (uint32_t w = lane; w < S * L::STRIDE; w += 64u) sreg0[w] = 0u;
+  if (owner) wl[lane] = p.state0_entry | (lane << SID_SHIFT);  // FPGA.v:134-147: current = {state 0}, per stream
+  uint32_t N = n_mine, Nn = 0, tog = 0;
+  uint32_t nxt[4];
+  load16(0, nxt);
+  wave_sync();
+  bool spilled = false;
+
+  for (uint32_t k = 0; k < p.n_passes && !spilled; k++) {
+    const bool consume = k < p.n_consume;
+    const uint32_t kk = k & 15u;
+    if (consume && kk == 0) {  // owners refill their stream's 16-byte window, fetch the next one
+      wave_sync();
+      if (owner) {
+        uint32_t* win = sreg0 + lane * L::STRIDE + 2u * L::FW;
+#pragma unroll
+        for (int q = 0; q < 4; q++) win[q] = nxt[q];
+      }
+      load16((k >> 4) + 1u, nxt);
+      wave_sync();
+    }
+    uint32_t* clist = wl + tog * L::CAPW;
+    uint32_t* nlist = wl + (tog ^ 1u) * L::CAPW;
+    const uint32_t fcur_off = tog * L::FW, fnext_off = (tog ^ 1u) * L::FW;
+    Nn = 0;
+
+    // exact check for a candidate whose filter bit was already set; wave-uniform call
+    auto resolve = [&](bool maybe, uint32_t t) {
+      uint64_t mm = __ballot(maybe);
+      while (mm) {
+        const uint32_t src = (uint32_t)__builtin_ctzll(mm);
+        mm &= mm - 1;
+        const uint32_t key = bcast(t, src) & KEY_MASK;
+        const uint32_t lim = Nn < L::CAPW ? Nn : L::CAPW;
+        bool found = false;
+        for (uint32_t q = lane; q < lim; q += 64u) found |= (nlist[q] & KEY_MASK) == key;
+        if (__ballot(found) == 0) {
+          if (lane == src && Nn < L::CAPW) nlist[Nn] = t;
+          Nn += 1;
+          wave_sync();
+        }
+      }
+    };
+    // one candidate per lane into the wave-wide next list; wave-uniform call
+    auto insert = [&](bool pred, uint32_t t, uint32_t* sreg) {
+      const uint32_t h = t & HMASK;
+      const uint32_t bit = 1u << (h & 31u);
+      uint32_t old = 0;
+      if (pred) old = atomicOr(&sreg[fnext_off + (h >> 5)], bit);
+      const bool fresh = pred && (old & bit) == 0;
+      const bool maybe = pred && (old & bit) != 0;
+      const uint64_t mf = __ballot(fresh);
+      const uint32_t slot = Nn + rank_below(mf);
+      if (fresh && slot < L::CAPW) nlist[slot] = t;
+      Nn += (uint32_t)__popcll(mf);
+      if (__ballot(maybe)) {
+        wave_sync();
+        resolve(maybe, t);
+      }
+    };
+
+    for (uint32_t b0 = 0; b0 < N; b0 += 64u) {
+      const uint32_t li = b0 + lane;
+      const bool valid = li < N;
+      const uint32_t e = valid ? clist[li] : 0u;
+      const uint32_t sid = (e >> SID_SHIFT) & 31u;
+      const uint32_t s = e & RXE_TGT_MASK;
+      const bool acc = valid && (e & RXE_ACCEPT);
+      uint32_t* sreg = sreg0 + sid * L::STRIDE;
+      {  // accept pulses
+        const uint64_t ma = __ballot(acc);
+        if (ma) {
+          uint32_t dummy = 0;
+          emit_events(p, acc, s, stream0 + sid, k, lane, dummy);
+          if (acc) atomicOr(&sreg[2u * L::FW + L::WINW], 1u << (k & 31u));
+        }
+      }
+      if (!consume) continue;
+      const uint32_t c = reinterpret_cast<const uint8_t*>(sreg + 2u * L::FW)[kk];  // input_char of that stream
+      if (valid) sreg[fcur_off + ((s & HMASK) >> 5)] = 0u;  // zero the filter word this entry went through
+      if (STATS && valid) { st_active += 1; st_edges += rp[s + 1] - rp[s]; }
+      const uint32_t x = (valid && !acc) ? symidx[(size_t)s * 256u + c] : 0u;  // current byte's slice of row s
+      // two candidates per lane: the state itself (self-loop) and the inline target; atomics back to back
+      const bool p0 = (x & RXE_SELF) != 0, p1 = (x & RXE_INLINE) != 0;
+      const uint32_t t1 = (x & (RXE_TGT_MASK | RXE_ACCEPT)) | (sid << SID_SHIFT);
+      const uint32_t h0 = e & HMASK, h1 = x & HMASK;
+      const uint32_t bt0 = 1u << (h0 & 31u), bt1 = 1u << (h1 & 31u);
+      uint32_t o0 = 0, o1 = 0;
+      if (p0) o0 = atomicOr(&sreg[fnext_off + (h0 >> 5)], bt0);
+      if (p1) o1 = atomicOr(&sreg[fnext_off + (h1 >> 5)], bt1);
+      const bool f0 = p0 && !(o0 & bt0), f1 = p1 && !(o1 & bt1);
+      const bool m0 = p0 && (o0 & bt0), m1 = p1 && (o1 & bt1);
+      const uint64_t mf0 = __ballot(f0), mf1 = __ballot(f1);
+      uint32_t slot = Nn + rank_below(mf0);
+      if (f0 && slot < L::CAPW) nlist[slot] = e;
+      Nn += (uint32_t)__popcll(mf0);
+      slot = Nn + rank_below(mf1);
+      if (f1 && slot < L::CAPW) nlist[slot] = t1;
+      Nn += (uint32_t)__popcll(mf1);
+      if (__ballot(m0 || m1)) {  // rare
+        wave_sync();
+        resolve(m0, e);
+        resolve(m1, t1);
+      }
+      if (__ballot(x & RXE_OVF)) {  // rows with several targets on this byte
+        const bool has = (x & RXE_OVF) != 0;
+        const uint32_t off = x & RXE_TGT_MASK;
+        const uint32_t cnt = has ? ovf[off] : 0u;
+        for (uint32_t q = 0; __ballot(q < cnt) != 0; q++) {
+          const bool act = q < cnt;
+          const uint32_t w = act ? ovf[off + 1u + q] : 0u;
+          insert(act, (w & (RXE_TGT_MASK | RXE_ACCEPT)) | (sid << SID_SHIFT), sreg);
+        }
+      }
+    }
+
+    if (consume) {
+      if (Nn > L::CAPW) {
+        // the wave-wide list cannot hold the next sets: hand ALL of this wave's streams (S_k, k) to the
+        // wave kernel.  S_k = the current list, still intact.
+        unsigned long long b = 0;
+        if (lane == 0) b = atomicAdd(p.spill_count, (unsigned long long)n_mine);
+        const uint32_t slot_base = bcast((uint32_t)b, 0);
+        wave_sync();
+        if (owner) {
+          const uint32_t slot = slot_base + lane;
+          slotw[lane] = slot;
+          p.spill_streams[slot] = stream0 + lane;
+          p.spill_k[slot] = k;
+          if (p.anymatch)
+            p.anymatch[(size_t)(stream0 + lane) * p.anymatch_stride + (k >> 5)] = sreg0[lane * L::STRIDE + 2u * L::FW + L::WINW];
+          uint32_t* row = p.spill_rows + (size_t)slot * p.nw64x2;
+          for (uint32_t w = 0; w < p.nw64x2; w++) row[w] = 0u;
+        }
+        __threadfence();
+        wave_sync();
+        for (uint32_t li = lane; li < N; li += 64u) {
+          const uint32_t e = clist[li];
+          const uint32_t sq = e & RXE_TGT_MASK;
+          uint32_t* row = p.spill_rows + (size_t)slotw[(e >> SID_SHIFT) & 31u] * p.nw64x2;
+          atomicOr(&row[sq >> 5], 1u << (sq & 31u));
+        }
+        spilled = true;
+      } else {
+        tog ^= 1u;  // current <- next (FPGA.v:733-737)
+        N = Nn;
+        wave_sync();
+      }
+    }
+    if (!spilled && p.anymatch && ((k & 31u) == 31u || k + 1 == p.n_passes)) {
+      wave_sync();
+      if (owner) {
+        uint32_t* am = sreg0 + lane * L::STRIDE + 2u * L::FW + L::WINW;
+        p.anymatch[(size_t)(stream0 + lane) * p.anymatch_stride + (k >> 5)] = *am;
+        *am = 0u;
+      }
+      wave_sync();
+    }
+  }
+  // final active sets: rows were zeroed by the host-side memset; set the listed bits
+  if (p.final_active && !spilled) {
+    const uint32_t* clist = wl + tog * L::CAPW;
+    for (uint32_t li = lane; li < N; li += 64u) {
+      const uint32_t e = clist[li];
+      const uint32_t sq = e & RXE_TGT_MASK;
+      uint32_t* row = p.final_active + (size_t)(stream0 + ((e >> SID_SHIFT) & 31u)) * p.nw64x2;
+      atomicOr(&row[sq >> 5], 1u << (sq & 31u));
+    }
+  }
+  if (STATS) {
+    if (st_active) atomicAdd(&p.counters[1], st_active);
+    if (st_edges) atomicAdd(&p.counters[2], st_edges);
+  }
+}
+
 }  // namespace
 
 // -------------------------------------------------------------------------------------------------
@@ -708,7 +948,8 @@ int rx_pick_launch(uint32_t kernel, uint32_t size, uint32_t n_streams, int cu_co
                    RxParams* p, RxLaunchCfg* cfg) {
   (void)cu_count;
   if (kernel == RX_KERNEL_AUTO) kernel = RX_KERNEL_SYM_GROUP;
-  if (kernel != RX_KERNEL_CSR_WAVE && kernel != RX_KERNEL_SYM_WAVE && kernel != RX_KERNEL_SYM_GROUP)
+  if (kernel != RX_KERNEL_CSR_WAVE && kernel != RX_KERNEL_SYM_WAVE && kernel != RX_KERNEL_SYM_GROUP &&
+      kernel != RX_KERNEL_SYM_PACK)
     return RX_EINVAL;
   const uint32_t nw32 = (size + 31u) / 32u;
   p->nw32 = nw32;
@@ -723,6 +964,10 @@ int rx_pick_launch(uint32_t kernel, uint32_t size, uint32_t n_streams, int cu_co
   cfg->lds_bytes = (uint32_t)(per_wave * wpb);
   uint32_t blocks = (n_streams + wpb - 1) / wpb;
   cfg->grid_blocks = blocks ? blocks : 1;
+  if (kernel == RX_KERNEL_SYM_PACK) {
+    const uint32_t gl = cfg->group_lanes;  // here: streams per wavefront
+    if (gl != 8 && gl != 16 && gl != 24 && gl != 32) cfg->group_lanes = 24;
+  }
   if (kernel == RX_KERNEL_SYM_GROUP) {
     const uint32_t gl = cfg->group_lanes;
     if (gl != 1 && gl != 2 && gl != 4 && gl != 8 && gl != 16) cfg->group_lanes = 4;
@@ -736,6 +981,11 @@ static int launch_one(K kern, const RxParams& p, uint32_t grid, uint32_t block, 
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
+  }
+  if (getenv("RX_DEBUG_OCCUPANCY")) {
+    int nb = 0;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, (int)block, lds);
+    fprintf(stderr, "[rxmatch] grid %u x %u threads, %u B LDS/block -> %d blocks/CU resident\n", grid, block, lds, nb);
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, p);
   return (int)hipGetLastError();
@@ -752,6 +1002,17 @@ static int launch_group(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s
                    : launch_one(rx_sym_group_kernel<G, false>, p, grid ? grid : 1, wpb * 64u, lds, s);
 }
 
+template <int S>
+static int launch_pack(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s) {
+  using L = PackLayout<S>;
+  const uint32_t wpb = 4;
+  const uint32_t waves = (p.n_streams + S - 1) / S;
+  const uint32_t grid = (waves + wpb - 1) / wpb;
+  const uint32_t lds = wpb * L::WAVE_WORDS * 4u;
+  return cfg.stats ? launch_one(rx_sym_pack_kernel<S, true>, p, grid ? grid : 1, wpb * 64u, lds, s)
+                   : launch_one(rx_sym_pack_kernel<S, false>, p, grid ? grid : 1, wpb * 64u, lds, s);
+}
+
 // returns a hipError_t value (0 = hipSuccess)
 int rx_launch(const RxParams& p, const RxLaunchCfg& cfg, void* hip_stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
@@ -762,9 +1023,15 @@ int rx_launch(const RxParams& p, const RxLaunchCfg& cfg, void* hip_stream) {
     case RX_KERNEL_SYM_WAVE:
       return cfg.stats ? launch_one(rx_sym_wave_kernel<true>, p, cfg.grid_blocks, cfg.block_threads, cfg.lds_bytes, s)
                        : launch_one(rx_sym_wave_kernel<false>, p, cfg.grid_blocks, cfg.block_threads, cfg.lds_bytes, s);
+    case RX_KERNEL_SYM_PACK:
     case RX_KERNEL_SYM_GROUP: {
       int e;
-      if (cfg.group_lanes == 1) e = launch_group<1>(p, cfg, s);
+      if (cfg.kernel == RX_KERNEL_SYM_PACK) {
+        if (cfg.group_lanes == 8) e = launch_pack<8>(p, cfg, s);
+        else if (cfg.group_lanes == 16) e = launch_pack<16>(p, cfg, s);
+        else if (cfg.group_lanes == 32) e = launch_pack<32>(p, cfg, s);
+        else e = launch_pack<24>(p, cfg, s);
+      } else if (cfg.group_lanes == 1) e = launch_group<1>(p, cfg, s);
       else if (cfg.group_lanes == 2) e = launch_group<2>(p, cfg, s);
       else if (cfg.group_lanes == 8) e = launch_group<8>(p, cfg, s);
       else if (cfg.group_lanes == 16) e = launch_group<16>(p, cfg, s);

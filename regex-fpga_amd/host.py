@@ -13,8 +13,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 MODE_FULL, MODE_TB_COMPAT = 0, 1
-KERNEL_AUTO, KERNEL_CSR_WAVE, KERNEL_SYM_WAVE, KERNEL_SYM_GROUP = 0, 1, 2, 3
-KERNEL_NAMES = {0: "auto", 1: "csr_wave", 2: "sym_wave", 3: "sym_group"}
+KERNEL_AUTO, KERNEL_CSR_WAVE, KERNEL_SYM_WAVE, KERNEL_SYM_GROUP, KERNEL_SYM_PACK = 0, 1, 2, 3, 4
+KERNEL_NAMES = {0: "auto", 1: "csr_wave", 2: "sym_wave", 3: "sym_group", 4: "sym_pack"}
 
 EVENT_DT = np.dtype([("stream", "<u4"), ("k", "<u4"), ("state", "<u4")])
 

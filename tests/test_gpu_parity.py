@@ -21,7 +21,9 @@ def kernels(rx):
     return [dict(kernel=rx.KERNEL_CSR_WAVE), dict(kernel=rx.KERNEL_SYM_WAVE),
             dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=1), dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=2),
             dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=4), dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=8),
-            dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=16), dict(kernel=rx.KERNEL_AUTO)]
+            dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=16), dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=8),
+            dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=16), dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=24),
+            dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=32), dict(kernel=rx.KERNEL_AUTO)]
 
 
 @pytest.fixture(scope="module")
