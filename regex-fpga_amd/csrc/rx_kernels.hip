@@ -947,7 +947,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
 int rx_pick_launch(uint32_t kernel, uint32_t size, uint32_t n_streams, int cu_count, size_t lds_per_cu,
                    RxParams* p, RxLaunchCfg* cfg) {
   (void)cu_count;
-  if (kernel == RX_KERNEL_AUTO) kernel = RX_KERNEL_SYM_GROUP;
+  if (kernel == RX_KERNEL_AUTO) kernel = RX_KERNEL_SYM_PACK;  // fastest parity-checked kernel
   if (kernel != RX_KERNEL_CSR_WAVE && kernel != RX_KERNEL_SYM_WAVE && kernel != RX_KERNEL_SYM_GROUP &&
       kernel != RX_KERNEL_SYM_PACK)
     return RX_EINVAL;
@@ -966,7 +966,7 @@ int rx_pick_launch(uint32_t kernel, uint32_t size, uint32_t n_streams, int cu_co
   cfg->grid_blocks = blocks ? blocks : 1;
   if (kernel == RX_KERNEL_SYM_PACK) {
     const uint32_t gl = cfg->group_lanes;  // here: streams per wavefront
-    if (gl != 8 && gl != 16 && gl != 24 && gl != 32) cfg->group_lanes = 24;
+    if (gl != 8 && gl != 12 && gl != 16 && gl != 20 && gl != 24 && gl != 32) cfg->group_lanes = 16;
   }
   if (kernel == RX_KERNEL_SYM_GROUP) {
     const uint32_t gl = cfg->group_lanes;
@@ -1028,9 +1028,11 @@ int rx_launch(const RxParams& p, const RxLaunchCfg& cfg, void* hip_stream) {
       int e;
       if (cfg.kernel == RX_KERNEL_SYM_PACK) {
         if (cfg.group_lanes == 8) e = launch_pack<8>(p, cfg, s);
-        else if (cfg.group_lanes == 16) e = launch_pack<16>(p, cfg, s);
+        else if (cfg.group_lanes == 12) e = launch_pack<12>(p, cfg, s);
+        else if (cfg.group_lanes == 20) e = launch_pack<20>(p, cfg, s);
+        else if (cfg.group_lanes == 24) e = launch_pack<24>(p, cfg, s);
         else if (cfg.group_lanes == 32) e = launch_pack<32>(p, cfg, s);
-        else e = launch_pack<24>(p, cfg, s);
+        else e = launch_pack<16>(p, cfg, s);
       } else if (cfg.group_lanes == 1) e = launch_group<1>(p, cfg, s);
       else if (cfg.group_lanes == 2) e = launch_group<2>(p, cfg, s);
       else if (cfg.group_lanes == 8) e = launch_group<8>(p, cfg, s);
