@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=16, help="cap on oracle threads (box share: 16 per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--all-kernels", action="store_true", help="also time the other kernels (extra keys)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL) for real multi-GPU runs; gloo only to rehearse ranks on fewer GPUs")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     return ap.parse_args()
 
 
@@ -78,11 +81,17 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if a.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
+    if a.same_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    rdev = dev if a.dist_backend == "nccl" else torch.device("cpu")  # where the report scalars are reduced
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if a.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo")
 
     wl = rx.workloads
     kern = {"auto": rx.KERNEL_AUTO, "csr_wave": rx.KERNEL_CSR_WAVE, "sym_wave": rx.KERNEL_SYM_WAVE,
@@ -131,7 +140,7 @@ def main():
     nk, ksum, kmin, kmax = plan.kernel_times()
     res = plan.download()
     assert res["stats"]["n_events"] == n_events, "timed kernel and stats kernel disagree"
-    sec, ev_total, bytes_total = rx.sharding.reduce_report(dist if world > 1 else None, dev, t1 - t0, n_events,
+    sec, ev_total, bytes_total = rx.sharding.reduce_report(dist if world > 1 else None, rdev, t1 - t0, n_events,
                                                            ns * sl)
     kavg_ms = ksum / max(nk, 1)
 

@@ -113,7 +113,9 @@ typedef struct rx_opts {
   uint32_t kernel;      /* RX_KERNEL_*                                                   */
   void* stream;         /* hipStream_t to launch on; NULL = the default stream           */
   uint64_t k_base;      /* added to every reported pass index (chunked streaming)        */
-  uint32_t collect_stats; /* !=0: also accumulate rx_stats.sum_active/sum_edges on device */
+  uint32_t collect_stats; /* 1: also accumulate rx_stats.sum_active/sum_edges on the device;
+                             2: additionally treat streams (2q, 2q+1) as Blk_Mem_tb's lock-step pair
+                                and predict its clock count -> rx_stats.tb_cycles (n_streams even)  */
   uint32_t group_lanes;   /* RX_KERNEL_SYM_GROUP: lanes per stream, 4 / 8 / 16; 0 = default   */
 } rx_opts;
 
@@ -136,6 +138,9 @@ typedef struct rx_stats {
   double h2d_ms, d2h_ms; /* hipEvent time of the copies rx_match() issued (0 for plans)   */
   uint32_t kernel_used;  /* RX_KERNEL_* actually launched                                 */
   uint32_t n_launches;
+  uint64_t tb_cycles;    /* collect_stats == 2: what `$display("Total no. cycles: %d", cycles)`
+                            (testbench_BLK_Mem.sv:84) prints for the pair(s), summed over pairs;
+                            0 if unavailable                                               */
 } rx_stats;
 
 /* All output arrays are caller-allocated and optional (NULL = not wanted). */

@@ -267,7 +267,7 @@ extern "C" int rx_plan_create(const rx_nfa* nfa, const rx_opts* opts, size_t max
   const size_t nw64x2 = 2 * (((size_t)size + 63) / 64);
   auto fail = [&](int code) { rx_plan_free(p); return code; };
 #define PLCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(hip_fail(e_, #call)); } while (0)
-  PLCHK(hipMalloc((void**)&p->d_counters, 4 * sizeof(unsigned long long)));
+  PLCHK(hipMalloc((void**)&p->d_counters, 8 * sizeof(unsigned long long)));
   PLCHK(hipMalloc((void**)&p->d_events, std::max<size_t>(events_cap, 1) * sizeof(rx_event)));
   PLCHK(hipMalloc((void**)&p->d_mct, (size_t)size * sizeof(unsigned long long)));
   if (p->want_mc) PLCHK(hipMalloc((void**)&p->d_mc, max_streams * size * sizeof(uint32_t)));
@@ -394,6 +394,12 @@ extern "C" int rx_plan_launch(rx_plan* p) {
   a.anymatch_stride = (uint32_t)p->am_stride;
   a.final_active = p->want_final ? p->d_final : nullptr;
   uint32_t kernel = p->opts.kernel;
+  const bool pair = p->opts.collect_stats == 2;
+  if (pair) {  // the testbench's clock count needs both streams of a pair in one wavefront: pack kernel only
+    if ((kernel != RX_KERNEL_AUTO && kernel != RX_KERNEL_SYM_PACK) || (p->n_streams & 1) || p->have_init) return RX_EINVAL;
+    kernel = RX_KERNEL_SYM_PACK;
+  }
+  a.pair_cycles = pair ? 1u : 0u;
   // a caller-supplied start set is a bitmask row: that is the wave kernel's dense form
   if (p->have_init && (kernel == RX_KERNEL_AUTO || kernel == RX_KERNEL_SYM_GROUP || kernel == RX_KERNEL_SYM_PACK))
     kernel = RX_KERNEL_SYM_WAVE;
@@ -416,7 +422,7 @@ extern "C" int rx_plan_launch(rx_plan* p) {
     a.spill_rows = p->d_spill_rows;
   }
 
-  HIPCHK(hipMemsetAsync(p->d_counters, 0, 4 * sizeof(unsigned long long), p->stream));
+  HIPCHK(hipMemsetAsync(p->d_counters, 0, 8 * sizeof(unsigned long long), p->stream));
   HIPCHK(hipMemsetAsync(p->d_mct, 0, (size_t)h.size * sizeof(unsigned long long), p->stream));
   if (p->want_mc) HIPCHK(hipMemsetAsync(p->d_mc, 0, p->n_streams * h.size * sizeof(uint32_t), p->stream));
   if (p->n_timed >= 4096) p->n_timed = 0;  // nobody is reading the times: recycle the pool
@@ -486,7 +492,7 @@ extern "C" int rx_plan_download(rx_plan* p, rx_result* res) {
   rc = rx_plan_sync(p, nullptr);
   if (rc) return rc;
   const RxHostNfa& h = p->nfa->h;
-  unsigned long long cnt[4] = {0, 0, 0, 0};
+  unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   HIPCHK(hipMemcpy(cnt, p->d_counters, sizeof(cnt), hipMemcpyDeviceToHost));
   rx_stats& st = res->stats;
   st = rx_stats{};
@@ -502,6 +508,10 @@ extern "C" int rx_plan_download(rx_plan* p, rx_result* res) {
     // + 1 bit per pass (per stream, rounded up to bytes) + 12 B per accept event
     st.alg_bytes = (uint64_t)p->params.n_consume * p->n_streams + 8 * st.sum_active + 4 * st.sum_edges +
                    (uint64_t)p->n_streams * ((st.n_passes + 7) / 8) + 12 * st.n_events;
+    // per pair 1 reset clock + per pass [size + sum over states active in either stream of
+    // (cost - 1)].  Only defined if no stream left the pack kernel (cnt[3] = handed-off streams).
+    if (p->params.pair_cycles && cnt[3] == 0)
+      st.tb_cycles = (p->n_streams / 2) * (1 + (uint64_t)p->params.n_consume * h.size) + cnt[4];
   }
   const size_t captured = (size_t)std::min<unsigned long long>(cnt[0], p->events_cap);
   res->events_overflow = cnt[0] > p->events_cap ? 1u : 0u;

@@ -51,7 +51,7 @@ struct RxParams {
   // outputs
   rx_event* events;
   uint32_t events_cap;
-  unsigned long long* counters; // [0] n_events  [1] sum_active  [2] sum_edges
+  unsigned long long* counters; // [0] n_events [1] sum_active [2] sum_edges [3] spilled streams [4] pair clock cost
   uint32_t* match_count;        // [n_streams][size] or null
   unsigned long long* match_count_total; // [size] or null
   uint32_t* anymatch;           // [n_streams][anymatch_stride] or null
@@ -67,6 +67,7 @@ struct RxParams {
   uint32_t resume;                  // wave kernel: 1 = walk the spill list instead of all streams
   uint32_t pin_state;               // group kernel: pinned state id, 0xFFFFFFFF = none
   uint32_t pin_degree;              // its row length (for the algorithmic-byte statistics)
+  uint32_t pair_cycles;             // stats build: also sum the FPGA clock cost of stream pairs (2q, 2q+1)
 };
 
 static constexpr uint32_t RX_GROUP_CAP = 24;     // group kernel: active-list capacity per stream

@@ -740,7 +740,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
   const uint32_t* __restrict__ rp = p.words;
   const uint32_t* __restrict__ symidx = p.symidx;
   const uint32_t* __restrict__ ovf = p.ovf;
-  unsigned long long st_active = 0, st_edges = 0;
+  unsigned long long st_active = 0, st_edges = 0, st_cost = 0;
 
   const uint32_t wave = blockIdx.x * wpb + wib;
   const uint32_t stream0 = wave * S;
@@ -844,7 +844,26 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       if (!consume) continue;
       const uint32_t c = reinterpret_cast<const uint8_t*>(sreg + 2u * L::FW)[kk];  // input_char of that stream
       if (valid) sreg[fcur_off + ((s & HMASK) >> 5)] = 0u;  // zero the filter word this entry went through
-      if (STATS && valid) { st_active += 1; st_edges += rp[s + 1] - rp[s]; }
+      if (STATS && valid) {
+        const uint32_t deg = rp[s + 1] - rp[s];
+        st_active += 1;
+        st_edges += deg;
+        if (p.pair_cycles) {
+          // Blk_Mem_tb scans both streams of a pair in lock-step (FPGA.v:158): a state active in either
+          // stream costs its clocks once.  Streams 2q / 2q+1 of the batch are such a pair; the odd
+          // stream skips states the even stream also holds.  cost(i) per SURVEY.md §3.2.
+          bool dup = false;
+          if (sid & 1u) {
+            const uint32_t key = (e ^ (1u << SID_SHIFT)) & KEY_MASK;
+            for (uint32_t q = 0; q < N; q++) dup |= (clist[q] & KEY_MASK) == key;
+          }
+          if (!dup) {
+            const uint32_t a = p.size + 1u + rp[s];
+            const uint32_t nlines = ((a + deg - 1u) >> 2) - (a >> 2) + 1u;
+            st_cost += 3u + ((s & 3u) == 3u ? 1u : 0u) + (deg == 0 ? 1u : nlines + 2u) + 1u - 1u;
+          }
+        }
+      }
       const uint32_t x = (valid && !acc) ? symidx[(size_t)s * 256u + c] : 0u;  // current byte's slice of row s
       // two candidates per lane: the state itself (self-loop) and the inline target; atomics back to back
       const bool p0 = (x & RXE_SELF) != 0, p1 = (x & RXE_INLINE) != 0;
@@ -936,6 +955,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
   if (STATS) {
     if (st_active) atomicAdd(&p.counters[1], st_active);
     if (st_edges) atomicAdd(&p.counters[2], st_edges);
+    if (st_cost) atomicAdd(&p.counters[4], st_cost);
   }
 }
 

@@ -67,6 +67,7 @@ int main(int argc, char** argv) {
   o.device = device;
   o.mode = full ? RX_MODE_FULL : RX_MODE_TB_COMPAT;
   o.kernel = kernel;
+  o.collect_stats = full ? 1 : 2;  // tb-compat: also predict the testbench's clock count
   rx_result r;
   memset(&r, 0, sizeof(r));
   r.struct_size = sizeof(r);
@@ -79,6 +80,12 @@ int main(int argc, char** argv) {
     for (uint32_t p = info.size; p-- > 0;)  // foreach over [size_range-1:0] iterates downwards
       if ((c[p] & 1023u) != 0)              // logic [9:0] counters
         printf("%s[%11d] = %4u\n", s == 0 ? "match_count" : "match_count_2", (int)p, c[p] & 1023u);
+  }
+  if (r.stats.tb_cycles) {  // $display($time,"\nTotal no. cycles: %d", cycles)  (testbench_BLK_Mem.sv:84)
+    const unsigned long long cyc = r.stats.tb_cycles;
+    // `int cycles` is a 32-bit signed int in the testbench (:19), so large counts wrap exactly like this cast
+    printf("%20llu\nTotal no. cycles: %11d\n", 10ull * cyc + 22ull, (int)(uint32_t)cyc);
+    fprintf(stderr, "rx_report: predicted FPGA clocks (unwrapped) %llu\n", cyc);
   }
   if (events)
     for (size_t e = 0; e < r.n_events; e++)

@@ -38,7 +38,7 @@ class _Stats(C.Structure):
     _fields_ = [("n_passes", C.c_uint64), ("n_events", C.c_uint64), ("sum_active", C.c_uint64),
                 ("sum_edges", C.c_uint64), ("alg_bytes", C.c_uint64), ("kernel_ms", C.c_double),
                 ("h2d_ms", C.c_double), ("d2h_ms", C.c_double), ("kernel_used", C.c_uint32),
-                ("n_launches", C.c_uint32)]
+                ("n_launches", C.c_uint32), ("tb_cycles", C.c_uint64)]
 
 
 class _Result(C.Structure):
@@ -212,7 +212,7 @@ def _mk_opts(device, mode, kernel, stream, k_base, collect_stats, group_lanes=0)
     o.device, o.mode, o.kernel = device, mode, kernel
     o.stream = stream
     o.k_base = k_base
-    o.collect_stats = 1 if collect_stats else 0
+    o.collect_stats = int(collect_stats)  # 0 / 1 (True) / 2 = + testbench pair clock model
     return o
 
 
@@ -250,7 +250,7 @@ class _Out:
                     stats=dict(n_passes=int(s.n_passes), n_events=int(s.n_events), sum_active=int(s.sum_active),
                                sum_edges=int(s.sum_edges), alg_bytes=int(s.alg_bytes), kernel_ms=s.kernel_ms,
                                h2d_ms=s.h2d_ms, d2h_ms=s.d2h_ms, kernel_used=int(s.kernel_used),
-                               n_launches=int(s.n_launches)))
+                               n_launches=int(s.n_launches), tb_cycles=int(s.tb_cycles)))
 
 
 def _as_rows(data):

@@ -13,8 +13,9 @@ from . import host
 TB_M_STOP = 200000  # testbench_BLK_Mem.sv:71
 
 
-def run(nfa, lo, hi, m_stop=TB_M_STOP, kernel=host.KERNEL_AUTO, device=-1, collect_stats=False):
-    """-> dict(match_count[2][size] (raw), events, report (str), stats)."""
+def run(nfa, lo, hi, m_stop=TB_M_STOP, kernel=host.KERNEL_AUTO, device=-1, collect_stats=2):
+    """-> dict(match_count[2][size] (raw), events, report (str), total_cycles, stats).
+    collect_stats=2 also evaluates the FPGA's clock count of the run on the GPU."""
     lo = np.asarray(lo, np.uint8)
     hi = np.asarray(hi, np.uint8)
     if lo.size < m_stop or hi.size < m_stop:
@@ -22,7 +23,10 @@ def run(nfa, lo, hi, m_stop=TB_M_STOP, kernel=host.KERNEL_AUTO, device=-1, colle
     rows = np.stack([lo[:m_stop], hi[:m_stop]])
     r = host.match(nfa, rows, mode=host.MODE_TB_COMPAT, kernel=kernel, device=device, want_match_count=True,
                    events_cap=1 << 20, collect_stats=collect_stats)
-    r["report"] = format_report(r["match_count"][0], r["match_count"][1])
+    cyc = r["stats"]["tb_cycles"] or None
+    r["total_cycles"] = cyc
+    # $time at the $display: last posedge at 10*cycles ns, then #1, #1 (byte load) and #20 (:52-73)
+    r["report"] = format_report(r["match_count"][0], r["match_count"][1], cyc, 10 * cyc + 22 if cyc else None)
     return r
 
 
@@ -36,6 +40,9 @@ def format_report(mc1, mc2, total_cycles=None, time_ns=None):
             if mc[p] != 0:
                 lines.append(f"{name}[{p:11d}] = {int(mc[p]):4d}")
     if total_cycles is not None:
+        # `int cycles` is a 32-bit signed SystemVerilog int (:19): snort_16's 2 188 184 738 clocks wrap to
+        # -2 106 782 558 in the real testbench's printout, and so do they here
+        wrapped = ((int(total_cycles) + 2**31) % 2**32) - 2**31
         lines.append(f"{(time_ns if time_ns is not None else 0):20d}")
-        lines.append(f"Total no. cycles: {total_cycles:11d}")
+        lines.append(f"Total no. cycles: {wrapped:11d}")
     return "\n".join(lines)
