@@ -85,6 +85,19 @@ int rx_nfa_get_info(const rx_nfa* nfa, rx_nfa_info* info);
 const uint32_t* rx_nfa_words(const rx_nfa* nfa, size_t* nwords);
 void rx_nfa_free(rx_nfa* nfa);
 
+/* ---- regex list -> CSR automaton (the step BEFORE the path; the reference ships tables only) ---- */
+enum { RX_RE_ICASE = 1, RX_RE_DOTALL = 2 };
+/* Compiles n patterns (PCRE subset, optionally written /regex/flags with flags i,s) into ONE automaton in
+ * the reference's table conventions (state 0 -> `.*` state 1 on every byte, accept = empty row, edge word
+ * = symbol<<24|target), ready for rx_match or rx_nfa_save_coe.  On RX_EFORMAT errbuf names the pattern. */
+int rx_compile_patterns(const char* const* patterns, size_t n, uint32_t flags, rx_nfa** out, char* errbuf,
+                        size_t errbuf_len);
+/* Pattern index an accept state reports (-1: not an accept state / table was not compiled here). */
+int rx_nfa_accept_pattern(const rx_nfa* nfa, uint32_t state, int32_t* pattern_index);
+/* Writes the table as a Xilinx .coe in the layout of Block_Mem/CSR_BlockMem_snort_16.coe
+ * (radix 16, one 128-bit line per row of text) so it can initialise the reference's ROM. */
+int rx_nfa_save_coe(const rx_nfa* nfa, const char* path);
+
 /* ---- traces ----------------------------------------------------------------------------- */
 /* $readmemh text (one 1-2 digit hex byte per line) -> malloc'ed byte array; release with rx_free. */
 int rx_trace_load_mem(const char* path, uint8_t** bytes, size_t* n);

@@ -41,7 +41,7 @@ extern "C" const char* rx_strerror(int code) {
     case RX_OK: return "ok";
     case RX_EINVAL: return "invalid argument";
     case RX_EIO: return "file could not be read";
-    case RX_EFORMAT: return "malformed .coe/.mem text";
+    case RX_EFORMAT: return "malformed input text (.coe / .mem / regex)";
     case RX_ENFA: return "word array is not a valid CSR automaton";
     case RX_ENOMEM: return "out of memory";
     case RX_ENODEVICE: return "no usable HIP device (librxmatch has no CPU fallback)";
@@ -68,6 +68,7 @@ struct rx_nfa {
   RxHostNfa h;
   std::mutex mu;
   std::map<int, DevTables> dev;  // HBM copies, one per device, uploaded on first use
+  std::vector<int32_t> accept_pattern;  // filled by rx_compile_patterns
 };
 
 extern "C" int rx_nfa_from_words(const uint32_t* words, size_t nwords, uint32_t size_or_0, rx_nfa** out) {
@@ -89,6 +90,32 @@ extern "C" int rx_nfa_load_coe(const char* path, uint32_t size_or_0, rx_nfa** ou
   rc = rxh_parse_coe_text(txt.data(), txt.size(), &w);
   if (rc) return rc;
   return rx_nfa_from_words(w.data(), w.size(), size_or_0, out);
+}
+
+extern "C" int rx_compile_patterns(const char* const* patterns, size_t n, uint32_t flags, rx_nfa** out, char* errbuf,
+                                   size_t errbuf_len) {
+  if (!patterns || !out || n == 0) return RX_EINVAL;
+  std::vector<uint32_t> words;
+  std::vector<int32_t> acc;
+  std::string err;
+  int rc = rxc_compile(patterns, n, flags, &words, &acc, &err);
+  if (errbuf && errbuf_len) snprintf(errbuf, errbuf_len, "%s", err.c_str());
+  if (rc) return rc;
+  rc = rx_nfa_from_words(words.data(), words.size(), (uint32_t)acc.size(), out);
+  if (rc) return rc;
+  (*out)->accept_pattern = std::move(acc);
+  return RX_OK;
+}
+
+extern "C" int rx_nfa_accept_pattern(const rx_nfa* nfa, uint32_t state, int32_t* pattern_index) {
+  if (!nfa || !pattern_index || state >= nfa->h.size) return RX_EINVAL;
+  *pattern_index = state < nfa->accept_pattern.size() ? nfa->accept_pattern[state] : -1;
+  return RX_OK;
+}
+
+extern "C" int rx_nfa_save_coe(const rx_nfa* nfa, const char* path) {
+  if (!nfa || !path) return RX_EINVAL;
+  return rxc_write_coe(path, nfa->h.words);
 }
 
 extern "C" int rx_nfa_get_info(const rx_nfa* nfa, rx_nfa_info* info) {

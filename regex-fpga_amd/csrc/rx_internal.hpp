@@ -108,4 +108,8 @@ int rxh_read_file(const char* path, std::string* out);
 int rxh_infer_size(const uint32_t* W, size_t nwords, uint32_t* size);
 int rxh_validate(const uint32_t* W, size_t nwords, uint32_t size);
 int rxh_build(const uint32_t* W, size_t nwords, uint32_t size_or_0, RxHostNfa* out);
+// rx_compile.cpp
+int rxc_compile(const char* const* patterns, size_t n, uint32_t flags, std::vector<uint32_t>* words,
+                std::vector<int32_t>* accept_pattern, std::string* err);
+int rxc_write_coe(const char* path, const std::vector<uint32_t>& words);
 int rxh_parse_mem_text(const char* text, size_t len, std::vector<uint8_t>* bytes);

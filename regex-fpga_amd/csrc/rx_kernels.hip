@@ -1004,7 +1004,7 @@ static int launch_one(K kern, const RxParams& p, uint32_t grid, uint32_t block, 
   }
   if (getenv("RX_DEBUG_OCCUPANCY")) {
     int nb = 0;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, (int)block, lds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, (int)block, lds);
     fprintf(stderr, "[rxmatch] grid %u x %u threads, %u B LDS/block -> %d blocks/CU resident\n", grid, block, lds, nb);
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, p);

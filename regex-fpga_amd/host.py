@@ -54,7 +54,9 @@ class _Info(C.Structure):
 
 
 # every symbol include/rxmatch.h declares
-ABI_SYMBOLS = ["rx_strerror", "rx_last_hip_error", "rx_abi_version", "rx_nfa_load_coe", "rx_nfa_from_words",
+RE_ICASE, RE_DOTALL = 1, 2
+
+ABI_SYMBOLS = ["rx_compile_patterns", "rx_nfa_accept_pattern", "rx_nfa_save_coe", "rx_strerror", "rx_last_hip_error", "rx_abi_version", "rx_nfa_load_coe", "rx_nfa_from_words",
                "rx_nfa_get_info", "rx_nfa_words", "rx_nfa_free", "rx_trace_load_mem", "rx_free", "rx_match",
                "rx_match_sharded", "rx_plan_create", "rx_plan_upload", "rx_plan_set_device_input",
                "rx_plan_set_init_active", "rx_plan_launch", "rx_plan_sync", "rx_plan_kernel_times", "rx_plan_download", "rx_plan_free",
@@ -105,6 +107,9 @@ def lib():
     L.rx_abi_version.restype = i32
     L.rx_nfa_load_coe.argtypes = [C.c_char_p, u32, C.POINTER(vp)]
     L.rx_nfa_from_words.argtypes = [vp, sz, u32, C.POINTER(vp)]
+    L.rx_compile_patterns.argtypes = [C.POINTER(C.c_char_p), sz, u32, C.POINTER(vp), C.c_char_p, sz]
+    L.rx_nfa_accept_pattern.argtypes = [vp, u32, C.POINTER(C.c_int32)]
+    L.rx_nfa_save_coe.argtypes = [vp, C.c_char_p]
     L.rx_nfa_get_info.argtypes = [vp, C.POINTER(_Info)]
     L.rx_nfa_words.restype = C.POINTER(C.c_uint32)
     L.rx_nfa_words.argtypes = [vp, C.POINTER(sz)]
@@ -180,6 +185,27 @@ class Nfa:
         h = C.c_void_p()
         _chk(lib().rx_nfa_from_words(w.ctypes.data_as(C.c_void_p), w.size, size, C.byref(h)), "rx_nfa_from_words")
         return cls(h)
+
+    @classmethod
+    def compile(cls, patterns, icase=False, dotall=False):
+        """rx_compile_patterns(): list of regex strings (bytes or str, optionally /re/flags) -> one automaton."""
+        pats = [p if isinstance(p, bytes) else p.encode("latin-1") for p in patterns]
+        arr = (C.c_char_p * len(pats))(*pats)
+        h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = lib().rx_compile_patterns(arr, len(pats), (RE_ICASE if icase else 0) | (RE_DOTALL if dotall else 0),
+                                       C.byref(h), err, 512)
+        if rc:
+            raise RxError(rc, f"rx_compile_patterns: {err.value.decode(errors='replace')}")
+        return cls(h)
+
+    def accept_pattern(self, state):
+        out = C.c_int32(-1)
+        _chk(lib().rx_nfa_accept_pattern(self._h, int(state), C.byref(out)), "rx_nfa_accept_pattern")
+        return out.value
+
+    def save_coe(self, path):
+        _chk(lib().rx_nfa_save_coe(self._h, os.fsencode(path)), f"rx_nfa_save_coe({path})")
 
     @property
     def words(self):
