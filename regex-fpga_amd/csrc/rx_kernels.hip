@@ -33,6 +33,12 @@
 
 namespace {
 
+// 64-lane ballot straight from the predicate (the generic __ballot goes through an int and costs two
+// extra VALU instructions per call)
+template <typename T>
+__device__ __forceinline__ uint64_t wballot(T pred) {
+  return __builtin_amdgcn_ballot_w64(pred != 0);
+}
 __device__ __forceinline__ uint32_t rank_below(uint64_t m) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
@@ -69,7 +75,7 @@ struct ByteFeed {
 // ---- accept pulses (FPGA.v:210-226 -> testbench_BLK_Mem.sv:61-69) -----------------------------
 __device__ __forceinline__ void emit_events(const RxParams& p, bool acc, uint32_t state, uint32_t stream,
                                             uint32_t k, uint32_t lane, uint32_t& am_word) {
-  const uint64_t ma = __ballot(acc);
+  const uint64_t ma = wballot(acc);
   if (ma == 0) return;
   const uint32_t cnt = (uint32_t)__popcll(ma);
   unsigned long long base = 0;
@@ -111,7 +117,7 @@ __device__ __forceinline__ void emit_target(StreamState& st, bool pred, uint32_t
     const uint32_t old = atomicOr(&st.nb[s >> 5], bit);  // ds_or_rtn_b32: next[t] <= 1 with dedup
     fresh = (old & bit) == 0;
   }
-  const uint64_t m = __ballot(fresh);
+  const uint64_t m = wballot(fresh);
   if (m) {
     const uint32_t slot = st.n_next + rank_below(m);
     if (fresh && slot < RX_LIST_CAP) st.nlist[slot] = t;
@@ -195,7 +201,7 @@ __device__ __forceinline__ void for_each_active(const RxParams& p, const StreamS
     for (uint32_t w0 = 0; w0 < p.nw32; w0 += 64u) {
       const uint32_t wi = w0 + lane;
       const uint32_t word = wi < p.nw32 ? st.cb[wi] : 0u;
-      uint64_t m = __ballot(word != 0u);
+      uint64_t m = wballot(word != 0u);
       while (m) {
         const uint32_t src = (uint32_t)__builtin_ctzll(m);
         m &= m - 1;
@@ -253,14 +259,14 @@ __global__ void __launch_bounds__(256) rx_csr_wave_kernel(const RxParams p) {
         if (STATS && valid) { st_active += 1; st_edges += deg; }
         // short rows: one lane per row, edges in sequence
         const bool small = valid && deg > 0 && deg <= RX_SMALL_DEG;
-        for (uint32_t j = 0; __ballot(small && j < deg) != 0; j++) {
+        for (uint32_t j = 0; wballot(small && j < deg) != 0; j++) {
           const bool act = small && j < deg;
           const uint32_t w = act ? col[base + j] : 0u;
           const bool hit = act && (w >> 24) == c;  // FPGA.v:264: transition == input_char
-          if (__ballot(hit)) emit_target(st, hit, w & RXE_TGT_MASK, lane);
+          if (wballot(hit)) emit_target(st, hit, w & RXE_TGT_MASK, lane);
         }
         // long rows: all 64 lanes sweep one row, 256 B per load
-        uint64_t mb = __ballot(valid && deg > RX_SMALL_DEG);
+        uint64_t mb = wballot(valid && deg > RX_SMALL_DEG);
         while (mb) {
           const uint32_t src = (uint32_t)__builtin_ctzll(mb);
           mb &= mb - 1;
@@ -270,7 +276,7 @@ __global__ void __launch_bounds__(256) rx_csr_wave_kernel(const RxParams p) {
             const bool act = j < d;
             const uint32_t w = act ? col[b + j] : 0u;
             const bool hit = act && (w >> 24) == c;
-            if (__ballot(hit)) emit_target(st, hit, w & RXE_TGT_MASK, lane);
+            if (wballot(hit)) emit_target(st, hit, w & RXE_TGT_MASK, lane);
           }
         }
       });
@@ -345,14 +351,14 @@ __global__ void __launch_bounds__(256) rx_sym_wave_kernel(const RxParams p) {
         if (STATS && valid && pulses) { st_active += 1; st_edges += rp[s + 1] - rp[s]; }  // hand-off pass already counted
         // the current byte's slice of row s: one dword
         const uint32_t ent = (valid && !acc) ? symidx[(size_t)s * 256u + c] : 0u;
-        if (__ballot(ent & RXE_SELF)) emit_target(st, (ent & RXE_SELF) != 0, s, lane);
-        if (__ballot(ent & RXE_INLINE))
+        if (wballot(ent & RXE_SELF)) emit_target(st, (ent & RXE_SELF) != 0, s, lane);
+        if (wballot(ent & RXE_INLINE))
           emit_target(st, (ent & RXE_INLINE) != 0, ent & (RXE_TGT_MASK | RXE_ACCEPT), lane);
-        if (__ballot(ent & RXE_OVF)) {
+        if (wballot(ent & RXE_OVF)) {
           const bool has = (ent & RXE_OVF) != 0;
           const uint32_t off = ent & RXE_TGT_MASK;
           const uint32_t cnt = has ? ovf[off] : 0u;
-          for (uint32_t j = 0; __ballot(j < cnt) != 0; j++) {
+          for (uint32_t j = 0; wballot(j < cnt) != 0; j++) {
             const bool act = j < cnt;
             const uint32_t t = act ? ovf[off + 1u + j] : 0u;
             emit_target(st, act, t, lane);
@@ -494,7 +500,7 @@ __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
     auto grp_bits = [&](uint64_t m) { return (uint32_t)(m >> gshift) & GMASK; };
     // accept pulses of up to one entry per lane; wave-uniform call
     auto pulses = [&](bool acc, uint32_t s) {
-      const uint64_t ma = __ballot(acc);
+      const uint64_t ma = wballot(acc);
       if (ma) {
         uint32_t dummy = 0;
         emit_events(p, acc, s, stream, k, lane, dummy);
@@ -504,8 +510,8 @@ __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
     // exact membership check for candidates whose filter bit was already set (true duplicate or hash
     // collision): one lane per group at a time scans the group's next list; wave-uniform call
     auto resolve = [&](bool maybe, uint32_t t) {
-      uint32_t gm = grp_bits(__ballot(maybe));
-      while (__ballot(gm != 0)) {
+      uint32_t gm = grp_bits(wballot(maybe));
+      while (wballot(gm != 0)) {
         const bool mine = maybe && gm != 0 && (gm & (0u - gm)) == (1u << j);
         bool found = false;
         if (mine) {
@@ -513,7 +519,7 @@ __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
           for (uint32_t q = 0; q < lim; q++) found |= ((nlist[q] ^ t) & RXE_TGT_MASK) == 0;
         }
         const bool app = mine && !found;
-        const uint32_t ga = grp_bits(__ballot(app));
+        const uint32_t ga = grp_bits(wballot(app));
         if (app && n_next < L::CAP) nlist[n_next] = t & (RXE_TGT_MASK | RXE_ACCEPT);
         n_next += ga ? 1u : 0u;
         gm &= gm - 1u;
@@ -523,7 +529,7 @@ __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
     // insert one candidate per lane into the group's next set; wave-uniform call (slow paths)
     auto insert = [&](bool pred, uint32_t t) {
       const bool topin = pred && (t & RXE_PIN) != 0;  // the pinned state is a flag, not a list entry
-      if (grp_bits(__ballot(topin))) pin_next = 1;
+      if (grp_bits(wballot(topin))) pin_next = 1;
       pred = pred && !topin;
       const uint32_t h = t & HMASK;
       const uint32_t bit = 1u << (h & 31u);
@@ -531,11 +537,11 @@ __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
       if (pred) old = atomicOr(&fnext[h >> 5], bit);
       const bool fresh = pred && (old & bit) == 0;
       const bool maybe = pred && (old & bit) != 0;
-      const uint32_t gb = grp_bits(__ballot(fresh));
+      const uint32_t gb = grp_bits(wballot(fresh));
       const uint32_t slot = n_next + (uint32_t)__popc(gb & gbelow);
       if (fresh && slot < L::CAP) nlist[slot] = t & (RXE_TGT_MASK | RXE_ACCEPT);
       n_next += (uint32_t)__popc(gb);
-      if (__ballot(maybe)) {
+      if (wballot(maybe)) {
         wave_sync();
         resolve(maybe, t);
       }
@@ -544,7 +550,7 @@ __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
       const bool has = (ent & RXE_OVF) != 0;
       const uint32_t off = ent & RXE_TGT_MASK;
       const uint32_t cnt = has ? ovf[off] : 0u;
-      for (uint32_t q = 0; __ballot(q < cnt) != 0; q++) {
+      for (uint32_t q = 0; wballot(q < cnt) != 0; q++) {
         const bool act = q < cnt;
         insert(act, act ? ovf[off + 1u + q] : 0u);
       }
@@ -554,7 +560,7 @@ __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
       for (uint32_t it = 0;; it++) {
         const uint32_t idx = it * G + j;
         const bool valid = alive && idx < n_cur;
-        if (__ballot(valid) == 0) break;
+        if (wballot(valid) == 0) break;
         const uint32_t e = valid ? clist[idx] : 0u;
         pulses(valid && (e & RXE_ACCEPT), e & RXE_TGT_MASK);
       }
@@ -571,7 +577,7 @@ __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
       if (v1) e1 = clist[i1];
       const uint32_t s0 = e0 & RXE_TGT_MASK, s1 = e1 & RXE_TGT_MASK;
       const bool a0 = v0 && (e0 & RXE_ACCEPT), a1 = v1 && (e1 & RXE_ACCEPT);
-      if (__ballot(a0 || a1)) { pulses(a0, s0); pulses(a1, s1); }
+      if (wballot(a0 || a1)) { pulses(a0, s0); pulses(a1, s1); }
       // these entries went through filter fcur: zero their words for the pass after next
       if (v0) fcur[(s0 & HMASK) >> 5] = 0u;
       if (v1) fcur[(s1 & HMASK) >> 5] = 0u;
@@ -590,7 +596,7 @@ __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
       bool p2 = (x1 & RXE_SELF) != 0, p3 = (x1 & RXE_INLINE) != 0;
       {
         const bool tp1 = p1 && (x0 & RXE_PIN), tp3 = p3 && (x1 & RXE_PIN);
-        if (grp_bits(__ballot(tp1 || tp3))) pin_next = 1;
+        if (grp_bits(wballot(tp1 || tp3))) pin_next = 1;
         p1 = p1 && !tp1;
         p3 = p3 && !tp3;
       }
@@ -604,8 +610,8 @@ __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
       // Phase D: slots by ballot + popcount of the group's bits
       const bool f0 = p0 && !(o0 & b0), f1 = p1 && !(o1 & b1), f2 = p2 && !(o2 & b2), f3 = p3 && !(o3 & b3);
       const bool m0 = p0 && (o0 & b0), m1 = p1 && (o1 & b1), m2 = p2 && (o2 & b2), m3 = p3 && (o3 & b3);
-      const uint32_t g0 = grp_bits(__ballot(f0)), g1 = grp_bits(__ballot(f1));
-      const uint32_t g2 = grp_bits(__ballot(f2)), g3 = grp_bits(__ballot(f3));
+      const uint32_t g0 = grp_bits(wballot(f0)), g1 = grp_bits(wballot(f1));
+      const uint32_t g2 = grp_bits(wballot(f2)), g3 = grp_bits(wballot(f3));
       uint32_t slot = n_next + (uint32_t)__popc(g0 & gbelow);
       if (f0 && slot < L::CAP) nlist[slot] = e0 & (RXE_TGT_MASK | RXE_ACCEPT);
       n_next += (uint32_t)__popc(g0);
@@ -618,23 +624,23 @@ __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
       slot = n_next + (uint32_t)__popc(g3 & gbelow);
       if (f3 && slot < L::CAP) nlist[slot] = x1 & (RXE_TGT_MASK | RXE_ACCEPT);
       n_next += (uint32_t)__popc(g3);
-      if (__ballot(m0 || m1 || m2 || m3)) {  // rare
+      if (wballot(m0 || m1 || m2 || m3)) {  // rare
         wave_sync();
         resolve(m0, e0);
         resolve(m1, x0);
         resolve(m2, e1);
         resolve(m3, x1);
       }
-      if (__ballot((x0 | x1) & RXE_OVF)) {  // rows with several targets on this byte
+      if (wballot((x0 | x1) & RXE_OVF)) {  // rows with several targets on this byte
         insert_ovf(x0);
         insert_ovf(x1);
       }
       // ---- streams with more than 2G virtual entries: one entry per lane per iteration ----------
-      if (__ballot(alive && n_cur + pinned > 2u * G)) {
+      if (wballot(alive && n_cur + pinned > 2u * G)) {
         for (uint32_t it = 2;; it++) {
           const uint32_t idx = it * G + j - pinned;
           const bool valid = alive && idx < n_cur;
-          if (__ballot(valid) == 0) break;
+          if (wballot(valid) == 0) break;
           const uint32_t e = valid ? clist[idx] : 0u;
           const uint32_t s = e & RXE_TGT_MASK;
           const bool acc = valid && (e & RXE_ACCEPT);
@@ -644,7 +650,7 @@ __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
           const uint32_t ent = (valid && !acc) ? symidx[(size_t)s * 256u + c] : 0u;
           insert((ent & RXE_SELF) != 0, e);
           insert((ent & RXE_INLINE) != 0, ent);
-          if (__ballot(ent & RXE_OVF)) insert_ovf(ent);
+          if (wballot(ent & RXE_OVF)) insert_ovf(ent);
         }
       }
     }
@@ -652,7 +658,7 @@ __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
     if (consume) {
       // next set too large for the group's list: hand the stream (S_k, k) to the wave kernel
       const bool spill = alive && n_next > L::CAP;
-      if (__ballot(spill)) {
+      if (wballot(spill)) {
         uint32_t slot = 0;
         if (spill && j == 0) slot = (uint32_t)atomicAdd(p.spill_count, 1ull);
         slot = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(gshift << 2), (int)slot);  // group leader's slot
@@ -792,7 +798,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
 
     // exact check for a candidate whose filter bit was already set; wave-uniform call
     auto resolve = [&](bool maybe, uint32_t t) {
-      uint64_t mm = __ballot(maybe);
+      uint64_t mm = wballot(maybe);
       while (mm) {
         const uint32_t src = (uint32_t)__builtin_ctzll(mm);
         mm &= mm - 1;
@@ -800,7 +806,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
         const uint32_t lim = Nn < L::CAPW ? Nn : L::CAPW;
         bool found = false;
         for (uint32_t q = lane; q < lim; q += 64u) found |= (nlist[q] & KEY_MASK) == key;
-        if (__ballot(found) == 0) {
+        if (wballot(found) == 0) {
           if (lane == src && Nn < L::CAPW) nlist[Nn] = t;
           Nn += 1;
           wave_sync();
@@ -815,11 +821,11 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       if (pred) old = atomicOr(&sreg[fnext_off + (h >> 5)], bit);
       const bool fresh = pred && (old & bit) == 0;
       const bool maybe = pred && (old & bit) != 0;
-      const uint64_t mf = __ballot(fresh);
+      const uint64_t mf = wballot(fresh);
       const uint32_t slot = Nn + rank_below(mf);
       if (fresh && slot < L::CAPW) nlist[slot] = t;
       Nn += (uint32_t)__popcll(mf);
-      if (__ballot(maybe)) {
+      if (wballot(maybe)) {
         wave_sync();
         resolve(maybe, t);
       }
@@ -834,7 +840,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       const bool acc = valid && (e & RXE_ACCEPT);
       uint32_t* sreg = sreg0 + sid * L::STRIDE;
       {  // accept pulses
-        const uint64_t ma = __ballot(acc);
+        const uint64_t ma = wballot(acc);
         if (ma) {
           uint32_t dummy = 0;
           emit_events(p, acc, s, stream0 + sid, k, lane, dummy);
@@ -875,23 +881,23 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       if (p1) o1 = atomicOr(&sreg[fnext_off + (h1 >> 5)], bt1);
       const bool f0 = p0 && !(o0 & bt0), f1 = p1 && !(o1 & bt1);
       const bool m0 = p0 && (o0 & bt0), m1 = p1 && (o1 & bt1);
-      const uint64_t mf0 = __ballot(f0), mf1 = __ballot(f1);
+      const uint64_t mf0 = wballot(f0), mf1 = wballot(f1);
       uint32_t slot = Nn + rank_below(mf0);
       if (f0 && slot < L::CAPW) nlist[slot] = e;
       Nn += (uint32_t)__popcll(mf0);
       slot = Nn + rank_below(mf1);
       if (f1 && slot < L::CAPW) nlist[slot] = t1;
       Nn += (uint32_t)__popcll(mf1);
-      if (__ballot(m0 || m1)) {  // rare
+      if (wballot(m0 || m1)) {  // rare
         wave_sync();
         resolve(m0, e);
         resolve(m1, t1);
       }
-      if (__ballot(x & RXE_OVF)) {  // rows with several targets on this byte
+      if (wballot(x & RXE_OVF)) {  // rows with several targets on this byte
         const bool has = (x & RXE_OVF) != 0;
         const uint32_t off = x & RXE_TGT_MASK;
         const uint32_t cnt = has ? ovf[off] : 0u;
-        for (uint32_t q = 0; __ballot(q < cnt) != 0; q++) {
+        for (uint32_t q = 0; wballot(q < cnt) != 0; q++) {
           const bool act = q < cnt;
           const uint32_t w = act ? ovf[off + 1u + q] : 0u;
           insert(act, (w & (RXE_TGT_MASK | RXE_ACCEPT)) | (sid << SID_SHIFT), sreg);

@@ -1,0 +1,79 @@
+// Address/UB-sanitised exercise of the host-side C/C++ (no HIP): the product's .coe/.mem parsers, size
+// inference, slice-index builder and regex compiler (csrc/rx_host.cpp, csrc/rx_compile.cpp), and the CPU
+// oracle's two models (oracle/rx_oracle.c, oracle/rx_cycle.c).  Built and run by tests/test_sanitizers.py.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../regex-fpga_amd/csrc/rx_internal.hpp"
+extern "C" {
+#include "../../oracle/rx_oracle.h"
+}
+
+#define CHECK(x) do { if (!(x)) { fprintf(stderr, "CHECK failed: %s (line %d)\n", #x, __LINE__); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+  if (argc < 4) return 2;
+  const char *coe = argv[1], *lo = argv[2], *hi = argv[3];
+  // product parsers + builder
+  std::string txt;
+  CHECK(rxh_read_file(coe, &txt) == RX_OK);
+  std::vector<uint32_t> W;
+  CHECK(rxh_parse_coe_text(txt.data(), txt.size(), &W) == RX_OK);
+  RxHostNfa h;
+  CHECK(rxh_build(W.data(), W.size(), 0, &h) == RX_OK);
+  CHECK(h.symidx.size() == (size_t)h.size * 256);
+  std::string ttxt;
+  CHECK(rxh_read_file(lo, &ttxt) == RX_OK);
+  std::vector<uint8_t> blo;
+  CHECK(rxh_parse_mem_text(ttxt.data(), ttxt.size(), &blo) == RX_OK);
+  // malformed inputs must be rejected, not crash
+  std::vector<uint32_t> junk;
+  CHECK(rxh_parse_coe_text("memory_initialization_radix=16;memory_initialization_vector=12 34;", 66, &junk) != RX_OK);
+  uint32_t sz = 0;
+  uint32_t bad[5] = {0, 3, 2, 1, 0};
+  CHECK(rxh_infer_size(bad, 5, &sz) != RX_OK);
+  // regex compiler
+  const char* pats[] = {"ab", "/he(l+)o/i", "a[0-9]{2,3}z", "^GET ", "x.*y", "(a|b)*c{2,}", "[^\\n]{0,8}q"};
+  std::vector<uint32_t> cw;
+  std::vector<int32_t> acc;
+  std::string err;
+  CHECK(rxc_compile(pats, 7, 0, &cw, &acc, &err) == RX_OK);
+  RxHostNfa hc;
+  CHECK(rxh_build(cw.data(), cw.size(), (uint32_t)acc.size(), &hc) == RX_OK);
+  const char* badp[] = {"a**(", "[z-a]", "a{5,2}", "\\", "(", "a|*"};
+  for (const char* b : badp) {
+    const char* one[] = {b};
+    CHECK(rxc_compile(one, 1, 0, &cw, &acc, &err) != RX_OK);
+  }
+  // oracle: parsers, functional batch, clock model, row probe
+  uint32_t* ow = nullptr; size_t on = 0; uint32_t osize = 0;
+  CHECK(orx_load_coe(coe, &ow, &on) == 0 && on == W.size() && memcmp(ow, W.data(), on * 4) == 0);
+  CHECK(orx_infer_size(ow, on, &osize) == 0 && osize == h.size);
+  uint8_t *olo = nullptr, *ohi = nullptr; size_t nlo = 0, nhi = 0;
+  CHECK(orx_load_mem(lo, &olo, &nlo) == 0 && orx_load_mem(hi, &ohi, &nhi) == 0);
+  CHECK(nlo == blo.size() && memcmp(olo, blo.data(), nlo) == 0);
+  const size_t n = 3000;
+  std::vector<uint8_t> rows(2 * n);
+  memcpy(rows.data(), olo, n); memcpy(rows.data() + n, ohi, n);
+  std::vector<orx_event> ev(4096);
+  uint64_t nev = 0; orx_stats st; int thr = 0;
+  std::vector<uint32_t> am(2 * ((n + 1 + 31) / 32));
+  std::vector<uint64_t> fin(2 * ((osize + 63) / 64)), tot(osize);
+  CHECK(orx_match_batch(ow, osize, rows.data(), 2, n, n, ORX_MODE_FULL, 2, nullptr, ev.data(), ev.size(), &nev, nullptr,
+                        tot.data(), am.data(), (n + 1 + 31) / 32, fin.data(), &st, &thr) == 0);
+  std::vector<uint32_t> mc1(osize), mc2(osize);
+  orx_tb_result tb;
+  CHECK(orx_tb_cycle(ow, on, osize, olo, ohi, nlo < nhi ? nlo : nhi, 400, 1, 0, 0, mc1.data(), mc2.data(), ev.data(), ev.size(),
+                     nullptr, &tb) == 0 && !tb.hung);
+  uint64_t pred = 0;
+  CHECK(orx_predict_cycles(ow, osize, olo, ohi, 399, &pred) == 0 && pred == tb.total_cycles);
+  uint32_t addrs[1024]; size_t na = 0; uint64_t clk = 0; int accd = 0;
+  for (uint32_t s = 0; s < osize; s += 97)
+    CHECK(orx_cycle_probe_row(ow, on, osize, s, 1, 0x61, addrs, 1024, &na, &clk, fin.data(), &accd) == 0);
+  orx_free(ow); orx_free(olo); orx_free(ohi);
+  printf("sanitize ok: %u states, %llu events, %llu clocks\n", osize, (unsigned long long)nev, (unsigned long long)tb.total_cycles);
+  return 0;
+}
