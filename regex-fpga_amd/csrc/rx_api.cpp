@@ -60,6 +60,8 @@ struct DevTables {
   uint32_t* symidx = nullptr;
   uint32_t* ovf = nullptr;
   uint32_t* accept_bits = nullptr;
+  uint32_t* symidx_c = nullptr;
+  uint32_t* byte_class = nullptr;
   int cu_count = 0;
   size_t lds_per_cu = 0;
 };
@@ -145,6 +147,8 @@ extern "C" void rx_nfa_free(rx_nfa* nfa) {
     (void)hipFree(kv.second.symidx);
     (void)hipFree(kv.second.ovf);
     (void)hipFree(kv.second.accept_bits);
+    (void)hipFree(kv.second.symidx_c);
+    (void)hipFree(kv.second.byte_class);
   }
   if (have_prev) (void)hipSetDevice(prev);
   delete nfa;
@@ -206,6 +210,12 @@ static int get_dev_tables(const rx_nfa* cnfa, int device, DevTables* out) {
   if ((rc = upload_vec(nfa->h.symidx, &t.symidx))) return rc;
   if ((rc = upload_vec(nfa->h.ovf, &t.ovf))) return rc;
   if ((rc = upload_vec(nfa->h.accept_bits, &t.accept_bits))) return rc;
+  if ((rc = upload_vec(nfa->h.symidx_c, &t.symidx_c))) return rc;
+  {
+    std::vector<uint32_t> bc(64);
+    memcpy(bc.data(), nfa->h.byte_class, 256);
+    if ((rc = upload_vec(bc, &t.byte_class))) return rc;
+  }
   nfa->dev[device] = t;
   *out = t;
   return RX_OK;
@@ -401,6 +411,9 @@ extern "C" int rx_plan_launch(rx_plan* p) {
   a.symidx = p->tab.symidx;
   a.ovf = p->tab.ovf;
   a.accept_bits = p->tab.accept_bits;
+  a.symidx_c = p->tab.symidx_c;
+  a.byte_class = p->tab.byte_class;
+  a.n_classes = h.n_classes;
   a.size = h.size;
   a.bytes = p->d_in;
   a.stride = p->stride;

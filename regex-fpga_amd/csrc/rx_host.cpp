@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <map>
 #include <sstream>
 
 #include "rx_internal.hpp"
@@ -170,6 +171,7 @@ int rxh_build(const uint32_t* W, size_t nwords, uint32_t size_or_0, RxHostNfa* o
   out->symidx.assign((size_t)size * 256, 0u);
   out->ovf.assign(1, 0u);
   std::vector<uint32_t> bucket[256];
+  std::map<std::vector<uint32_t>, uint32_t> ovf_at;
   for (uint32_t i = 0; i < size; i++) {
     const uint32_t base = rp[i], deg = rp[i + 1] - base;
     if (deg == 0) continue;
@@ -189,14 +191,39 @@ int rxh_build(const uint32_t* W, size_t nwords, uint32_t size_or_0, RxHostNfa* o
       if (b.size() == 1) {
         ent |= RXE_INLINE | b[0] | (is_acc(b[0]) ? RXE_ACCEPT : 0u) | pin_flag(b[0]);
       } else if (b.size() >= 2) {
-        const size_t off = out->ovf.size();
-        if (off + b.size() + 1 > RXE_TGT_MASK) return RX_ECAPACITY;
-        out->ovf.push_back((uint32_t)b.size());
-        for (uint32_t t : b) out->ovf.push_back(t | (is_acc(t) ? RXE_ACCEPT : 0u) | pin_flag(t));
-        ent |= RXE_OVF | (uint32_t)off;
+        auto it = ovf_at.find(b);  // identical target sets share one list, so equal slices are equal words
+        if (it == ovf_at.end()) {
+          const size_t off = out->ovf.size();
+          if (off + b.size() + 1 > RXE_TGT_MASK) return RX_ECAPACITY;
+          out->ovf.push_back((uint32_t)b.size());
+          for (uint32_t t : b) out->ovf.push_back(t | (is_acc(t) ? RXE_ACCEPT : 0u) | pin_flag(t));
+          it = ovf_at.emplace(b, (uint32_t)off).first;
+        }
+        ent |= RXE_OVF | it->second;
       }
       out->symidx[(size_t)i * 256 + c] = ent;
     }
+  }
+  // ---- byte classes: bytes whose column of the slice index is identical behave identically in every
+  // state, so the index can be stored per class (snort_16: 74 classes, l7: 164) ------------------------
+  {
+    std::map<std::vector<uint32_t>, uint32_t> class_of_col;
+    std::vector<uint32_t> colv(size);
+    std::vector<int> rep;  // representative byte of each class
+    for (int c = 0; c < 256; c++) {
+      for (uint32_t i = 0; i < size; i++) colv[i] = out->symidx[(size_t)i * 256 + c];
+      auto it = class_of_col.find(colv);
+      if (it == class_of_col.end()) {
+        it = class_of_col.emplace(colv, (uint32_t)rep.size()).first;
+        rep.push_back(c);
+      }
+      out->byte_class[c] = (uint8_t)it->second;
+    }
+    out->n_classes = (uint32_t)rep.size();
+    out->symidx_c.assign((size_t)size * out->n_classes, 0u);
+    for (uint32_t i = 0; i < size; i++)
+      for (uint32_t k = 0; k < out->n_classes; k++)
+        out->symidx_c[(size_t)i * out->n_classes + k] = out->symidx[(size_t)i * 256 + rep[k]];
   }
   return RX_OK;
 }

@@ -33,6 +33,9 @@ struct RxParams {
   // automaton in HBM — `words` is the .coe content unchanged: row_ptr = words, col = words+size+1
   const uint32_t* words;
   const uint32_t* symidx;       // [size][256] slice index (null for the CSR kernel)
+  const uint32_t* symidx_c;     // [size][n_classes] the same index per byte class (pack kernel)
+  const uint32_t* byte_class;   // [64] words = 256 bytes: class id of every input byte
+  uint32_t n_classes;
   const uint32_t* ovf;          // overflow target lists of the slice index
   const uint32_t* accept_bits;  // [nw32] bit i set iff deg(i) == 0
   uint32_t size;
@@ -96,6 +99,10 @@ struct RxHostNfa {
   std::vector<uint32_t> symidx;       // size*256
   std::vector<uint32_t> ovf;          // ovf[0] unused so that offset 0 never occurs
   std::vector<uint32_t> accept_bits;  // ceil(size/32)
+  // bytes with identical slice-index columns form one class; symidx_c is the index stored per class
+  uint8_t byte_class[256] = {0};
+  uint32_t n_classes = 0;
+  std::vector<uint32_t> symidx_c;     // size*n_classes
   // A state with a self-loop on all 256 bytes stays active forever once entered.  The one state 0 feeds on
   // the most bytes (snort_16: state 1, the `.*` state) is "pinned": targets equal to it carry RXE_PIN.
   uint32_t pin_state = 0xFFFFFFFFu;

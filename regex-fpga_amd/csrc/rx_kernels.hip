@@ -729,6 +729,7 @@ struct PackLayout {
   static constexpr uint32_t WINW = 4;                       // 16 input bytes per stream
   static constexpr uint32_t STRIDE = 2u * FW + WINW + 1u;   // + any-match word; odd => banks spread
   static constexpr uint32_t WAVE_WORDS = 2u * CAPW + S * STRIDE + S;  // lists, stream regions, spill slots
+  static constexpr uint32_t CMAPW = 64;                     // byte -> class map (256 bytes), shared by the block
 };
 
 template <int S, bool STATS>
@@ -740,13 +741,19 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wib = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-  uint32_t* wl = lds + (size_t)wib * L::WAVE_WORDS;  // [2][CAPW] wave-wide lists
+  uint32_t* cmapw = lds;                              // [64] byte -> class
+  const uint8_t* cmap = reinterpret_cast<const uint8_t*>(cmapw);
+  uint32_t* wl = lds + L::CMAPW + (size_t)wib * L::WAVE_WORDS;  // [2][CAPW] wave-wide lists
   uint32_t* sreg0 = wl + 2u * L::CAPW;               // [S][STRIDE]: filters[2][FW], window[WINW], am word
   uint32_t* slotw = sreg0 + S * L::STRIDE;           // [S] spill slots
   const uint32_t* __restrict__ rp = p.words;
-  const uint32_t* __restrict__ symidx = p.symidx;
+  const uint32_t* __restrict__ symidx = p.symidx_c;
+  const uint32_t ncls = p.n_classes;
   const uint32_t* __restrict__ ovf = p.ovf;
   unsigned long long st_active = 0, st_edges = 0, st_cost = 0;
+
+  for (uint32_t w = threadIdx.x; w < L::CMAPW; w += blockDim.x) cmapw[w] = p.byte_class[w];
+  __syncthreads();  // the only block-wide barrier; the waves never meet again
 
   const uint32_t wave = blockIdx.x * wpb + wib;
   const uint32_t stream0 = wave * S;
@@ -783,10 +790,14 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
     const uint32_t kk = k & 15u;
     if (consume && kk == 0) {  // owners refill their stream's 16-byte window, fetch the next one
       wave_sync();
-      if (owner) {
+      if (owner) {  // bytes -> byte classes on the way into the window
         uint32_t* win = sreg0 + lane * L::STRIDE + 2u * L::FW;
 #pragma unroll
-        for (int q = 0; q < 4; q++) win[q] = nxt[q];
+        for (int q = 0; q < 4; q++) {
+          const uint32_t v = nxt[q];
+          win[q] = (uint32_t)cmap[v & 0xFFu] | ((uint32_t)cmap[(v >> 8) & 0xFFu] << 8) |
+                   ((uint32_t)cmap[(v >> 16) & 0xFFu] << 16) | ((uint32_t)cmap[v >> 24] << 24);
+        }
       }
       load16((k >> 4) + 1u, nxt);
       wave_sync();
@@ -848,7 +859,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
         }
       }
       if (!consume) continue;
-      const uint32_t c = reinterpret_cast<const uint8_t*>(sreg + 2u * L::FW)[kk];  // input_char of that stream
+      const uint32_t c = reinterpret_cast<const uint8_t*>(sreg + 2u * L::FW)[kk];  // class of that stream's input_char
       if (valid) sreg[fcur_off + ((s & HMASK) >> 5)] = 0u;  // zero the filter word this entry went through
       if (STATS && valid) {
         const uint32_t deg = rp[s + 1] - rp[s];
@@ -870,7 +881,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
           }
         }
       }
-      const uint32_t x = (valid && !acc) ? symidx[(size_t)s * 256u + c] : 0u;  // current byte's slice of row s
+      const uint32_t x = (valid && !acc) ? symidx[s * ncls + c] : 0u;  // current byte's slice of row s
       // two candidates per lane: the state itself (self-loop) and the inline target; atomics back to back
       const bool p0 = (x & RXE_SELF) != 0, p1 = (x & RXE_INLINE) != 0;
       const uint32_t t1 = (x & (RXE_TGT_MASK | RXE_ACCEPT)) | (sid << SID_SHIFT);
@@ -1034,7 +1045,7 @@ static int launch_pack(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s)
   const uint32_t wpb = 4;
   const uint32_t waves = (p.n_streams + S - 1) / S;
   const uint32_t grid = (waves + wpb - 1) / wpb;
-  const uint32_t lds = wpb * L::WAVE_WORDS * 4u;
+  const uint32_t lds = (L::CMAPW + wpb * L::WAVE_WORDS) * 4u;
   return cfg.stats ? launch_one(rx_sym_pack_kernel<S, true>, p, grid ? grid : 1, wpb * 64u, lds, s)
                    : launch_one(rx_sym_pack_kernel<S, false>, p, grid ? grid : 1, wpb * 64u, lds, s);
 }
