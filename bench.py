@@ -41,7 +41,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams-per-gpu", type=int, default=65536)
     ap.add_argument("--stream-len", type=int, default=1024)
-    ap.add_argument("--workload", choices=["T", "U"], default="T")
+    ap.add_argument("--workload", choices=["T", "U", "R"], default="T",
+                    help="T trace windows (headline), U uniform bytes, R synthetic ~10k-state ruleset stand-in")
     ap.add_argument("--kernel", default="auto", choices=["auto", "csr_wave", "sym_wave", "sym_group", "sym_pack"])
     ap.add_argument("--group-lanes", type=int, default=0)
     ap.add_argument("--cpu-threads", type=int, default=16, help="cap on oracle threads (box share: 16 per GPU)")
@@ -57,6 +58,8 @@ def make_rows(rx, workload, first, count, stream_len, traces):
     wl = rx.workloads
     if workload == "T":
         return wl.trace_windows(traces[0], traces[1], count, stream_len, first=first)
+    if workload == "R":
+        return wl.ruleset_traffic(traces, count, stream_len, first=first)
     return wl.uniform(count, stream_len, first=first)
 
 
@@ -96,8 +99,12 @@ def main():
     wl = rx.workloads
     kern = {"auto": rx.KERNEL_AUTO, "csr_wave": rx.KERNEL_CSR_WAVE, "sym_wave": rx.KERNEL_SYM_WAVE,
             "sym_group": rx.KERNEL_SYM_GROUP, "sym_pack": rx.KERNEL_SYM_PACK}[a.kernel]
-    nfa = rx.Nfa.load_coe(wl.SNORT_COE)
-    traces = (rx.load_mem(wl.TRACES[("snort_16", "lo")]), rx.load_mem(wl.TRACES[("snort_16", "hi")]))
+    if a.workload == "R":  # BASELINE configs[4] stand-in: synthetic ruleset compiled by rx_compile_patterns
+        traces = wl.synthetic_ruleset()
+        nfa = rx.Nfa.compile(traces)
+    else:
+        nfa = rx.Nfa.load_coe(wl.SNORT_COE)
+        traces = (rx.load_mem(wl.TRACES[("snort_16", "lo")]), rx.load_mem(wl.TRACES[("snort_16", "hi")]))
     ns, sl = a.streams_per_gpu, a.stream_len
     first = rank * ns  # contiguous block per rank (sharding.shard_range of world*ns streams)
     rows = make_rows(rx, a.workload, first, ns, sl, traces)
@@ -163,9 +170,11 @@ def main():
         "metric": "input Gbit/s matched vs snort_16 NFA", "value": round(gbit, 3), "unit": "Gbit/s",
         "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(sec / a.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": f"snort_16 CSR NFA (9514 states, 79856 edges), {ns} x {sl} B streams per GPU, "
-                               f"distribution {a.workload} ({'windows of the reference snort_16 traces' if a.workload == 'T' else 'splitmix64 uniform bytes'}), "
-                               f"full mode from reset, BASELINE configs[2]",
+        "config": {"workload": (f"snort_16 CSR NFA (9514 states, 79856 edges), {ns} x {sl} B streams per GPU, "
+                                f"distribution {a.workload} ({'windows of the reference snort_16 traces' if a.workload == 'T' else 'splitmix64 uniform bytes'}), "
+                                f"full mode from reset, BASELINE configs[2]") if a.workload != "R" else
+                               (f"STAND-IN for configs[4]: synthetic 700-pattern ruleset compiled to one CSR NFA "
+                                f"({nfa.size} states, {nfa.nnz} edges), {ns} x {sl} B pseudo-traffic streams per GPU"),
                    "kernel": kernel_used, "streams_per_gpu": ns, "stream_len": sl,
                    "parallelism": f"streams sharded over {a.gpus} GPU(s), no collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -198,8 +207,8 @@ def main():
 
     if not a.no_cpu_baseline:
         from oracle import orx  # checker / reported CPU baseline only
-        W = orx.load_coe(wl.SNORT_COE)
-        size = orx.infer_size(W)
+        W = nfa.words if a.workload == "R" else orx.load_coe(wl.SNORT_COE)
+        size = nfa.size if a.workload == "R" else orx.infer_size(W)
         # threads = this process's CPU share (capped), sample sized for ~15 s of CPU work
         nthr = max(1, min(len(os.sched_getaffinity(0)), a.cpu_threads))
         t = time.perf_counter()
@@ -223,12 +232,14 @@ def main():
         # RTL-equivalent baseline: the clock-accurate restatement of FPGA.v + Blk_Mem_tb, 1 core, no skip
         m = 3000
         t = time.perf_counter()
-        cyc = orx.tb_cycle(W, size, traces[0], traces[1], m, skip_idle=False)
+        cyc = orx.tb_cycle(W, size, rows[0], rows[1] if ns > 1 else rows[0], min(m, sl), skip_idle=False) if a.workload == "R" else \
+            orx.tb_cycle(W, size, traces[0], traces[1], m, skip_idle=False)
+        m = min(m, sl) if a.workload == "R" else m
         cyc_s = time.perf_counter() - t
         out["cpu_baseline"]["rtl_model"] = {
             "kind": "clock-accurate C restatement of FPGA.v (no Verilator in the image)", "cores": 1,
             "clocks": cyc["total_cycles"], "clocks_per_s": round(cyc["total_cycles"] / cyc_s),
-            "input_bit_s": round(2 * (m - 1) * 8 / cyc_s), "sample": f"first {m} bytes of the snort_16 lo+hi traces"}
+            "input_bit_s": round(2 * (m - 1) * 8 / cyc_s), "sample": f"first {m} bytes of " + ("streams 0+1" if a.workload == "R" else "the snort_16 lo+hi traces")}
         assert ok, "GPU events differ from the oracle on the CPU-baseline sample"
     print(json.dumps(out))
     if world > 1:

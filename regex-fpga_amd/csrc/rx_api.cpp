@@ -247,6 +247,9 @@ struct rx_plan {
   // current batch
   size_t n_streams = 0, stream_len = 0, stride = 0;
   bool have_input = false, launched = false;
+  bool auto_decided = false;   // RX_KERNEL_AUTO: the probe has run for the current batch
+  uint32_t auto_kernel = RX_KERNEL_SYM_PACK;
+  double probe_active = 0;     // active states per stream-byte seen by the probe
   RxParams params{};
   RxLaunchCfg cfg{};
   // one hipEvent pair per launch since the last rx_plan_kernel_times() call
@@ -345,6 +348,7 @@ static int set_batch(rx_plan* p, size_t n_streams, size_t stream_len, size_t str
   p->stride = stride;
   p->have_input = true;
   p->launched = false;
+  p->auto_decided = false;
   return RX_OK;
 }
 
@@ -398,14 +402,8 @@ extern "C" int rx_plan_set_init_active(rx_plan* p, const uint64_t* init_active) 
   return RX_OK;
 }
 
-extern "C" int rx_plan_launch(rx_plan* p) {
-  if (!p) return RX_EINVAL;
-  if (!p->have_input) return RX_ESTATE;
-  int dev;
-  int rc = bind_device(p->device, &dev);
-  if (rc) return rc;
+static void fill_common(rx_plan* p, RxParams& a) {
   const RxHostNfa& h = p->nfa->h;
-  RxParams& a = p->params;
   a = RxParams{};
   a.words = p->tab.words;
   a.symidx = p->tab.symidx;
@@ -417,17 +415,75 @@ extern "C" int rx_plan_launch(rx_plan* p) {
   a.size = h.size;
   a.bytes = p->d_in;
   a.stride = p->stride;
+  a.state0_entry = (h.accept_bits[0] & 1u) ? RXE_ACCEPT : 0u;
+  a.nw64x2 = 2u * ((h.size + 63u) / 64u);
+  a.counters = p->d_counters;
+  a.pin_state = h.pin_state;
+  a.pin_degree = h.pin_state != 0xFFFFFFFFu ? h.row_ptr()[h.pin_state + 1] - h.row_ptr()[h.pin_state] : 0;
+}
+
+static int ensure_spill_area(rx_plan* p, RxParams& a) {
+  if (!p->d_spill_rows) {  // hand-off area group/pack kernel -> wave kernel, sized so that it cannot overflow
+    HIPCHK(hipMalloc((void**)&p->d_spill_streams, p->max_streams * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void**)&p->d_spill_k, p->max_streams * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void**)&p->d_spill_rows, p->max_streams * (size_t)a.nw64x2 * sizeof(uint32_t)));
+  }
+  a.spill_count = p->d_counters + 3;
+  a.spill_streams = p->d_spill_streams;
+  a.spill_k = p->d_spill_k;
+  a.spill_rows = p->d_spill_rows;
+  return RX_OK;
+}
+
+// RX_KERNEL_AUTO: the fastest kernel depends on how many states are active per stream, which depends on
+// the input.  Probe: the pack kernel's statistics build over a corner of the batch (<= 512 streams x <= 1024
+// bytes, no outputs), then: small active sets -> pack kernel, larger ones -> wavefront-per-stream slice kernel.
+static int auto_probe(rx_plan* p) {
+  p->auto_kernel = RX_KERNEL_SYM_PACK;
+  p->probe_active = 0;
+  if (p->n_streams * p->stream_len < (256u << 10)) return RX_OK;  // tiny batch: not worth a probe
+  RxParams a;
+  fill_common(p, a);
+  a.n_streams = (uint32_t)std::min<size_t>(p->n_streams, 512);
+  a.stream_len = (uint32_t)std::min<size_t>(p->stream_len, 1024);
+  a.n_passes = a.stream_len + 1;
+  a.n_consume = a.stream_len;
+  RxLaunchCfg cfg{};
+  cfg.group_lanes = 16;
+  int rc = rx_pick_launch(RX_KERNEL_SYM_PACK, a.size, a.n_streams, p->tab.cu_count, p->tab.lds_per_cu, &a, &cfg);
+  if (rc) return rc;
+  cfg.stats = true;
+  if ((rc = ensure_spill_area(p, a))) return rc;
+  HIPCHK(hipMemsetAsync(p->d_counters, 0, 8 * sizeof(unsigned long long), p->stream));
+  hipError_t e = (hipError_t)rx_launch(a, cfg, p->stream);
+  if (e != hipSuccess) return hip_fail(e, "probe launch");
+  unsigned long long cnt[8];
+  HIPCHK(hipMemcpyAsync(cnt, p->d_counters, sizeof(cnt), hipMemcpyDeviceToHost, p->stream));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  const double units = (double)a.n_streams * std::max<uint32_t>(a.stream_len, 1);
+  p->probe_active = (double)cnt[1] / units;
+  const double spilled = (double)cnt[3] / a.n_streams;
+  if (p->probe_active > 6.0 || spilled > 0.02) p->auto_kernel = RX_KERNEL_SYM_WAVE;
+  return RX_OK;
+}
+
+extern "C" int rx_plan_launch(rx_plan* p) {
+  if (!p) return RX_EINVAL;
+  if (!p->have_input) return RX_ESTATE;
+  int dev;
+  int rc = bind_device(p->device, &dev);
+  if (rc) return rc;
+  const RxHostNfa& h = p->nfa->h;
+  RxParams& a = p->params;
+  fill_common(p, a);
   a.n_streams = (uint32_t)p->n_streams;
   a.stream_len = (uint32_t)p->stream_len;
   a.n_passes = (uint32_t)passes_for(p->stream_len, p->opts.mode);
   a.n_consume = p->opts.mode == RX_MODE_TB_COMPAT ? a.n_passes : (uint32_t)p->stream_len;
   a.k_base = (uint32_t)p->opts.k_base;
-  a.state0_entry = (h.accept_bits[0] & 1u) ? RXE_ACCEPT : 0u;
-  a.nw64x2 = 2u * ((h.size + 63u) / 64u);
   a.init_active = p->have_init ? p->d_init : nullptr;
   a.events = p->events_cap ? p->d_events : nullptr;
   a.events_cap = (uint32_t)p->events_cap;
-  a.counters = p->d_counters;
   a.match_count = p->want_mc ? p->d_mc : nullptr;
   a.match_count_total = p->d_mct;
   a.anymatch = p->want_am ? p->d_am : nullptr;
@@ -440,6 +496,13 @@ extern "C" int rx_plan_launch(rx_plan* p) {
     kernel = RX_KERNEL_SYM_PACK;
   }
   a.pair_cycles = pair ? 1u : 0u;
+  if (kernel == RX_KERNEL_AUTO && !pair && !p->have_init) {
+    if (!p->auto_decided) {
+      if ((rc = auto_probe(p))) return rc;
+      p->auto_decided = true;
+    }
+    kernel = p->auto_kernel;
+  }
   // a caller-supplied start set is a bitmask row: that is the wave kernel's dense form
   if (p->have_init && (kernel == RX_KERNEL_AUTO || kernel == RX_KERNEL_SYM_GROUP || kernel == RX_KERNEL_SYM_PACK))
     kernel = RX_KERNEL_SYM_WAVE;
@@ -448,19 +511,7 @@ extern "C" int rx_plan_launch(rx_plan* p) {
   if (rc) return rc;
   p->cfg.stats = p->opts.collect_stats != 0;
   const bool two_tier = p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK;
-  if (two_tier) {
-    if (!p->d_spill_rows) {  // hand-off area group kernel -> wave kernel, sized so that it cannot overflow
-      HIPCHK(hipMalloc((void**)&p->d_spill_streams, p->max_streams * sizeof(uint32_t)));
-      HIPCHK(hipMalloc((void**)&p->d_spill_k, p->max_streams * sizeof(uint32_t)));
-      HIPCHK(hipMalloc((void**)&p->d_spill_rows, p->max_streams * (size_t)a.nw64x2 * sizeof(uint32_t)));
-    }
-    a.pin_state = h.pin_state;
-    a.pin_degree = h.pin_state != 0xFFFFFFFFu ? h.row_ptr()[h.pin_state + 1] - h.row_ptr()[h.pin_state] : 0;
-    a.spill_count = p->d_counters + 3;
-    a.spill_streams = p->d_spill_streams;
-    a.spill_k = p->d_spill_k;
-    a.spill_rows = p->d_spill_rows;
-  }
+  if (two_tier && (rc = ensure_spill_area(p, a))) return rc;
 
   HIPCHK(hipMemsetAsync(p->d_counters, 0, 8 * sizeof(unsigned long long), p->stream));
   HIPCHK(hipMemsetAsync(p->d_mct, 0, (size_t)h.size * sizeof(unsigned long long), p->stream));

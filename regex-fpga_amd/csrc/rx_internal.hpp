@@ -83,6 +83,7 @@ struct RxLaunchCfg {
   uint32_t block_threads;
   uint32_t grid_blocks;
   uint32_t lds_bytes;      // dynamic LDS per block
+  int cu_count;
   bool stats;
 };
 

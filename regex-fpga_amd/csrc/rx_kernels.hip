@@ -354,13 +354,17 @@ __global__ void __launch_bounds__(256) rx_sym_wave_kernel(const RxParams p) {
         if (wballot(ent & RXE_SELF)) emit_target(st, (ent & RXE_SELF) != 0, s, lane);
         if (wballot(ent & RXE_INLINE))
           emit_target(st, (ent & RXE_INLINE) != 0, ent & (RXE_TGT_MASK | RXE_ACCEPT), lane);
-        if (wballot(ent & RXE_OVF)) {
-          const bool has = (ent & RXE_OVF) != 0;
-          const uint32_t off = ent & RXE_TGT_MASK;
-          const uint32_t cnt = has ? ovf[off] : 0u;
-          for (uint32_t j = 0; wballot(j < cnt) != 0; j++) {
-            const bool act = j < cnt;
-            const uint32_t t = act ? ovf[off + 1u + j] : 0u;
+        // rows with several targets on this byte: the whole wave expands one list at a time, 64 targets
+        // per step (coalesced), instead of one lane walking it alone
+        uint64_t mo = wballot(ent & RXE_OVF);
+        while (mo) {
+          const uint32_t src = (uint32_t)__builtin_ctzll(mo);
+          mo &= mo - 1;
+          const uint32_t off = bcast(ent & RXE_TGT_MASK, src);
+          const uint32_t cnt = ovf[off];
+          for (uint32_t j0 = 0; j0 < cnt; j0 += 64u) {
+            const bool act = j0 + lane < cnt;
+            const uint32_t t = act ? ovf[off + 1u + j0 + lane] : 0u;
             emit_target(st, act, t, lane);
           }
         }
@@ -401,8 +405,9 @@ __global__ void __launch_bounds__(256) rx_sym_wave_kernel(const RxParams p) {
 // resume mode (S_k as a bitmask row + k), so results stay exact for any automaton / input.
 template <int G>
 struct GroupLayout {
-  static constexpr uint32_t FW = RX_GROUP_FILTER_WORDS;
-  static constexpr uint32_t CAP = RX_GROUP_CAP;
+  // wider groups are for automata/inputs with larger active sets: longer lists, larger filters
+  static constexpr uint32_t FW = G >= 16 ? 4u * RX_GROUP_FILTER_WORDS : (G == 8 ? 2u * RX_GROUP_FILTER_WORDS : RX_GROUP_FILTER_WORDS);
+  static constexpr uint32_t CAP = G >= 16 ? 128u : (G == 8 ? 64u : RX_GROUP_CAP);
   static constexpr uint32_t BUFW = 4u * G;  // byte window: 16 B per lane
   static constexpr uint32_t RAW = 2u * FW + 2u * CAP + BUFW;
   // region stride == G (mod 2G): within a 32-lane half the groups' list slots (g*REGION + j) fall on
@@ -904,14 +909,19 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
         resolve(m0, e);
         resolve(m1, t1);
       }
-      if (wballot(x & RXE_OVF)) {  // rows with several targets on this byte
-        const bool has = (x & RXE_OVF) != 0;
-        const uint32_t off = x & RXE_TGT_MASK;
-        const uint32_t cnt = has ? ovf[off] : 0u;
-        for (uint32_t q = 0; wballot(q < cnt) != 0; q++) {
-          const bool act = q < cnt;
-          const uint32_t w = act ? ovf[off + 1u + q] : 0u;
-          insert(act, (w & (RXE_TGT_MASK | RXE_ACCEPT)) | (sid << SID_SHIFT), sreg);
+      // rows with several targets on this byte: the wave expands one such list at a time, 64 targets per step
+      uint64_t mo = wballot(x & RXE_OVF);
+      while (mo) {
+        const uint32_t src = (uint32_t)__builtin_ctzll(mo);
+        mo &= mo - 1;
+        const uint32_t off = bcast(x & RXE_TGT_MASK, src);
+        const uint32_t osid = bcast(sid, src);
+        uint32_t* oreg = sreg0 + osid * L::STRIDE;
+        const uint32_t cnt = ovf[off];
+        for (uint32_t q0 = 0; q0 < cnt; q0 += 64u) {
+          const bool act = q0 + lane < cnt;
+          const uint32_t w = act ? ovf[off + 1u + q0 + lane] : 0u;
+          insert(act, (w & (RXE_TGT_MASK | RXE_ACCEPT)) | (osid << SID_SHIFT), oreg);
         }
       }
     }
@@ -983,7 +993,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
 // -------------------------------------------------------------------------------------------------
 int rx_pick_launch(uint32_t kernel, uint32_t size, uint32_t n_streams, int cu_count, size_t lds_per_cu,
                    RxParams* p, RxLaunchCfg* cfg) {
-  (void)cu_count;
+  cfg->cu_count = cu_count;
   if (kernel == RX_KERNEL_AUTO) kernel = RX_KERNEL_SYM_PACK;  // fastest parity-checked kernel
   if (kernel != RX_KERNEL_CSR_WAVE && kernel != RX_KERNEL_SYM_WAVE && kernel != RX_KERNEL_SYM_GROUP &&
       kernel != RX_KERNEL_SYM_PACK)
@@ -1082,7 +1092,8 @@ int rx_launch(const RxParams& p, const RxLaunchCfg& cfg, void* hip_stream) {
       r.resume = 1;
       const uint32_t wpb = cfg.block_threads / 64u;
       uint32_t grid = (p.n_streams + wpb - 1) / wpb;
-      if (grid > 512u) grid = 512u;
+      const uint32_t fill = (cfg.cu_count > 0 ? (uint32_t)cfg.cu_count : 256u) * 8u;  // enough blocks to fill the chip
+      if (grid > fill) grid = fill;
       return cfg.stats ? launch_one(rx_sym_wave_kernel<true>, r, grid ? grid : 1, cfg.block_threads, cfg.lds_bytes, s)
                        : launch_one(rx_sym_wave_kernel<false>, r, grid ? grid : 1, cfg.block_threads, cfg.lds_bytes, s);
     }

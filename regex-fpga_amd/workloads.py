@@ -58,3 +58,51 @@ def uniform(n_streams, stream_len, first=0):
             state, z = _splitmix64_next(state)
             out[:, q] = z
     return out.view(np.uint8).reshape(n_streams, nq * 8)[:, :stream_len].copy()
+
+
+# ---- stand-in for BASELINE configs[4] ("full Snort community ruleset compiled to one CSR NFA") ----------
+# No rules and no network exist offline, so the ruleset is synthetic: seeded content-style patterns compiled by
+# the product's own regex compiler (csrc/rx_compile.cpp) into one ~10k-state automaton.  Reported as a
+# stand-in, never as the real ruleset.
+_RULE_WORDS = [b"admin", b"passwd", b"select", b"union", b"cmd.exe", b"/etc/", b"script", b"GET ", b"POST ",
+               b"User-Agent", b"Content-Length", b"%00", b"../", b"eval(", b"base64", b"login", b"root", b"shell",
+               b"wget ", b"chmod "]
+
+
+def synthetic_ruleset(n=700, seed=20261004):
+    import re
+    rng = np.random.default_rng(seed)
+    alnum = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz0123456789", np.uint8)
+    pats = []
+    for _ in range(n):
+        a = _RULE_WORDS[int(rng.integers(len(_RULE_WORDS)))]
+        tail = bytes(rng.choice(alnum, size=int(rng.integers(3, 9))))
+        kind = int(rng.integers(5))
+        esc = re.escape(a)
+        if kind == 0:
+            p = esc + tail
+        elif kind == 1:
+            p = esc + b"[^\\n]{0,8}" + tail
+        elif kind == 2:
+            p = b"/" + esc + b"\\s*=\\s*" + tail + b"/i"
+        elif kind == 3:
+            p = esc + b"(" + tail[:3] + b"|" + tail[3:] + b"x)+\\d"
+        else:
+            p = tail + b"[0-9a-f]{4}" + esc
+        pats.append(p)
+    return pats
+
+
+def ruleset_traffic(pats, n_streams, stream_len, first=0, seed=7):
+    """Printable pseudo-traffic with rule fragments mixed in (about one fragment per 40 bytes)."""
+    out = np.empty((n_streams, stream_len), np.uint8)
+    frags = [p[:10] for p in pats[:64]] + _RULE_WORDS
+    for i in range(n_streams):
+        rng = np.random.default_rng(seed + 1000003 * (first + i))
+        row = rng.integers(32, 127, size=stream_len, dtype=np.uint8)
+        for _ in range(max(stream_len // 40, 1)):
+            f = np.frombuffer(frags[int(rng.integers(len(frags)))], np.uint8)
+            at = int(rng.integers(0, max(stream_len - len(f), 1)))
+            row[at:at + len(f)] = f[:stream_len - at]
+        out[i] = row
+    return out
