@@ -551,13 +551,19 @@ __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
         resolve(maybe, t);
       }
     };
+    // rows with several targets on this byte: the G lanes of the group expand one such list at a time,
+    // G targets per step, instead of the owning lane walking it alone; wave-uniform call
     auto insert_ovf = [&](uint32_t ent) {
-      const bool has = (ent & RXE_OVF) != 0;
-      const uint32_t off = ent & RXE_TGT_MASK;
-      const uint32_t cnt = has ? ovf[off] : 0u;
-      for (uint32_t q = 0; wballot(q < cnt) != 0; q++) {
-        const bool act = q < cnt;
-        insert(act, act ? ovf[off + 1u + q] : 0u);
+      uint32_t gm = grp_bits(wballot(ent & RXE_OVF));  // lanes of MY group that hold an overflow slice
+      while (wballot(gm != 0)) {
+        const uint32_t srcj = gm ? (uint32_t)__builtin_ctz(gm) : 0u;
+        const uint32_t off = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((gshift + srcj) << 2), (int)(ent & RXE_TGT_MASK));
+        const uint32_t cnt = gm ? ovf[off] : 0u;
+        for (uint32_t q0 = 0; wballot(q0 < cnt) != 0; q0 += G) {
+          const bool act = q0 + j < cnt;
+          insert(act, act ? ovf[off + 1u + q0 + j] : 0u);
+        }
+        gm &= gm - 1u;
       }
     };
 

@@ -156,3 +156,27 @@ def test_compiled_ruleset_on_gpu(rx, orx):
         assert np.array_equal(got["events"], ref["events"].astype(got["events"].dtype)), kern
         assert np.array_equal(got["final_active"], ref["final_active"]) and np.array_equal(got["match_count"], ref["match_count"])
         assert got["stats"]["alg_bytes"] == ref["stats"]["alg_bytes"]
+
+
+@pytest.mark.gpu
+def test_auto_picks_wave_kernel_for_large_active_sets(rx, orx):
+    """RX_KERNEL_AUTO probes the batch: on the ruleset stand-in (about 14 active states per byte) it must choose
+    the wavefront-per-stream slice kernel, on snort_16 trace windows the pack kernel — with identical results."""
+    wl = rx.workloads
+    pats = wl.synthetic_ruleset()
+    nfa = rx.Nfa.compile(pats)
+    rows = wl.ruleset_traffic(pats, 640, 1024)
+    ref = orx.match_batch(nfa.words, nfa.size, rows)
+    got = rx.match(nfa, rows, collect_stats=True)
+    assert rx.host.KERNEL_NAMES[got["stats"]["kernel_used"]] == "sym_wave"
+    assert got["n_events"] == ref["n_events"] and np.array_equal(got["events"], ref["events"].astype(got["events"].dtype))
+    assert np.array_equal(got["final_active"], ref["final_active"]) and got["stats"]["alg_bytes"] == ref["stats"]["alg_bytes"]
+    for kern in (dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=16), dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=8),
+                 dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=8)):
+        g2 = rx.match(nfa, rows, collect_stats=True, **kern)
+        assert np.array_equal(g2["events"], got["events"]) and np.array_equal(g2["final_active"], got["final_active"]), kern
+        assert g2["stats"]["alg_bytes"] == ref["stats"]["alg_bytes"], kern
+    snort = rx.Nfa.load_coe(wl.SNORT_COE)
+    lo, hi = rx.load_mem(wl.TRACES[("snort_16", "lo")]), rx.load_mem(wl.TRACES[("snort_16", "hi")])
+    got = rx.match(snort, wl.trace_windows(lo, hi, 640, 1024))
+    assert rx.host.KERNEL_NAMES[got["stats"]["kernel_used"]] == "sym_pack"
