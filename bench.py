@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=16, help="cap on oracle threads (box share: 16 per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--all-kernels", action="store_true", help="also time the other kernels (extra keys)")
+    ap.add_argument("--no-second-distribution", action="store_true", help="skip the extra distribution-U measurement")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) for real multi-GPU runs; gloo only to rehearse ranks on fewer GPUs")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -186,6 +187,29 @@ def main():
         "accept_events_per_launch": ev_total,
         "h2d_inclusive_gbit_s": round(8.0 * ns * sl / (h2d_s + kavg_ms * 1e-3) / 1e9, 3),
     }
+
+    if a.workload == "T" and not a.no_second_distribution:
+        # SURVEY.md §8d asks for both seeded distributions; T above is the headline, U is reported beside it
+        urows = make_rows(rx, "U", first, ns, sl, traces)
+        d_u = torch.from_numpy(urows).to(dev)
+        up = rx.Plan(nfa, ns, sl, mode=rx.MODE_FULL, kernel=kern, device=local, stream=stream, events_cap=1 << 22,
+                     collect_stats=True, group_lanes=a.group_lanes)
+        up.set_device_input(d_u.data_ptr(), ns, sl, sl, keepalive=d_u)
+        up.launch()
+        ualg = up.download()["stats"]["alg_bytes"]
+        up.close()
+        up = rx.Plan(nfa, ns, sl, mode=rx.MODE_FULL, kernel=kern, device=local, stream=stream, events_cap=1 << 22,
+                     group_lanes=a.group_lanes)
+        up.set_device_input(d_u.data_ptr(), ns, sl, sl, keepalive=d_u)
+        time_kernel(up, 2)
+        uavg, umin, umax = time_kernel(up, max(a.steps // 2, 3))
+        ures = up.download()
+        out["distribution_U"] = {"gbit_s": round(8.0 * ns * sl / (uavg * 1e-3) / 1e9, 3), "kernel_ms_avg": round(uavg, 4),
+                                 "alg_bytes_per_launch": ualg, "eff_GBs": round(ualg / (uavg * 1e-3) / 1e9, 2),
+                                 "kernel": rx.host.KERNEL_NAMES[ures["stats"]["kernel_used"]],
+                                 "accept_events_per_launch": ures["stats"]["n_events"]}
+        up.close()
+        del d_u
 
     if a.all_kernels:
         extra = {}

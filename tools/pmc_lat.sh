@@ -2,7 +2,7 @@
 # average VMEM / LDS instruction latency of the match kernel: tools/pmc_lat.sh <tag> [bench args]
 TAG=${1:-q}; shift || true
 OUT=gpurun_out/pl_$TAG; mkdir -p $OUT; export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-second-distribution $*"
 rocprofv3 -L > $OUT/counters.txt 2>&1
 rocprofv3 --pmc SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_BUSY_CU_CYCLES --output-format csv -d $OUT/a -- python3 bench.py $ARGS > $OUT/a.log 2>&1
 rocprofv3 --pmc TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_BUSY_avr TCP_GATE_EN1_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum --output-format csv -d $OUT/b -- python3 bench.py $ARGS > $OUT/b.log 2>&1
