@@ -257,26 +257,37 @@ __global__ void __launch_bounds__(256) rx_csr_wave_kernel(const RxParams p) {
         emit_events(p, valid && deg == 0, s, stream, k, lane, am_word);
         if (!consume) return;
         if (STATS && valid) { st_active += 1; st_edges += deg; }
-        // short rows: one lane per row, edges in sequence
+        // short rows: one lane per row; all of the row's edge words are requested before any is examined
         const bool small = valid && deg > 0 && deg <= RX_SMALL_DEG;
-        for (uint32_t j = 0; wballot(small && j < deg) != 0; j++) {
-          const bool act = small && j < deg;
-          const uint32_t w = act ? col[base + j] : 0u;
-          const bool hit = act && (w >> 24) == c;  // FPGA.v:264: transition == input_char
-          if (wballot(hit)) emit_target(st, hit, w & RXE_TGT_MASK, lane);
+        if (wballot(small)) {
+          uint32_t w[RX_SMALL_DEG];
+#pragma unroll
+          for (uint32_t j = 0; j < RX_SMALL_DEG; j++) w[j] = (small && j < deg) ? col[base + j] : 0u;
+#pragma unroll
+          for (uint32_t j = 0; j < RX_SMALL_DEG; j++) {
+            const bool hit = small && j < deg && (w[j] >> 24) == c;  // FPGA.v:264: transition == input_char
+            if (wballot(hit)) emit_target(st, hit, w[j] & RXE_TGT_MASK, lane);
+          }
         }
-        // long rows: all 64 lanes sweep one row, 256 B per load
+        // long rows: all 64 lanes sweep one row, 256 B per load, up to five loads (320 edges) in flight
         uint64_t mb = wballot(valid && deg > RX_SMALL_DEG);
         while (mb) {
           const uint32_t src = (uint32_t)__builtin_ctzll(mb);
           mb &= mb - 1;
           const uint32_t b = bcast(base, src), d = bcast(deg, src);
-          for (uint32_t j0 = 0; j0 < d; j0 += 64u) {
-            const uint32_t j = j0 + lane;
-            const bool act = j < d;
-            const uint32_t w = act ? col[b + j] : 0u;
-            const bool hit = act && (w >> 24) == c;
-            if (wballot(hit)) emit_target(st, hit, w & RXE_TGT_MASK, lane);
+          for (uint32_t j0 = 0; j0 < d; j0 += 320u) {
+            uint32_t w[5];
+#pragma unroll
+            for (uint32_t u = 0; u < 5; u++) {
+              const uint32_t j = j0 + u * 64u + lane;
+              w[u] = j < d ? col[b + j] : 0u;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 5; u++) {
+              const uint32_t j = j0 + u * 64u + lane;
+              const bool hit = j < d && (w[u] >> 24) == c;
+              if (wballot(hit)) emit_target(st, hit, w[u] & RXE_TGT_MASK, lane);
+            }
           }
         }
       });
