@@ -107,16 +107,18 @@ void rx_free(void* p);
 enum { RX_MODE_FULL = 0, RX_MODE_TB_COMPAT = 1 };
 
 enum {
-  RX_KERNEL_AUTO = 0,     /* fastest parity-checked kernel for this automaton            */
-  RX_KERNEL_CSR_WAVE = 1, /* wavefront-per-stream over the state-major CSR as loaded     */
-  RX_KERNEL_SYM_WAVE = 2, /* wavefront-per-stream over the per-(state,symbol) slice index */
-  RX_KERNEL_SYM_GROUP = 3 /* G lanes per stream (64/G streams per wavefront), slice index;
-                             streams whose active set outgrows the group's list are finished by
-                             RX_KERNEL_SYM_WAVE in the same call                            */
-  ,
-  RX_KERNEL_SYM_PACK = 4  /* S streams per wavefront, lanes assigned dynamically to one wave-wide
-                             list of (stream,state) entries; rx_opts.group_lanes = S (8/16/24/32);
-                             same hand-off to RX_KERNEL_SYM_WAVE                             */
+  RX_KERNEL_AUTO = 0,     /* probe, then choose: on the first launch for a batch the plan runs the pack
+                             kernel's statistics build over a corner of it (<= 512 streams x <= 1 KB; this
+                             synchronises the stream once) and picks RX_KERNEL_SYM_PACK for small active
+                             sets (<= 6 states per stream-byte), RX_KERNEL_SYM_WAVE otherwise          */
+  RX_KERNEL_CSR_WAVE = 1, /* wavefront-per-stream over the state-major CSR exactly as loaded         */
+  RX_KERNEL_SYM_WAVE = 2, /* wavefront-per-stream over the per-(state,symbol) slice index            */
+  RX_KERNEL_SYM_GROUP = 3, /* G lanes per stream (64/G streams per wavefront), slice index;
+                             rx_opts.group_lanes = G (1/2/4/8/16, default 4); streams whose active set
+                             outgrows the group's list are finished by RX_KERNEL_SYM_WAVE in the same call */
+  RX_KERNEL_SYM_PACK = 4  /* S streams per wavefront, the 64 lanes assigned dynamically to one wave-wide
+                             list of (stream,state) entries; rx_opts.group_lanes = S (8/12/16/20/24/32,
+                             default 16); same hand-off to RX_KERNEL_SYM_WAVE                         */
 };
 
 typedef struct rx_opts {
@@ -129,7 +131,7 @@ typedef struct rx_opts {
   uint32_t collect_stats; /* 1: also accumulate rx_stats.sum_active/sum_edges on the device;
                              2: additionally treat streams (2q, 2q+1) as Blk_Mem_tb's lock-step pair
                                 and predict its clock count -> rx_stats.tb_cycles (n_streams even)  */
-  uint32_t group_lanes;   /* RX_KERNEL_SYM_GROUP: lanes per stream, 4 / 8 / 16; 0 = default   */
+  uint32_t group_lanes;   /* SYM_GROUP: lanes per stream; SYM_PACK: streams per wavefront; 0 = default */
 } rx_opts;
 
 /* One accept pulse: `state` was active and accepting in pass `k` of stream `stream`.
