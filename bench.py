@@ -216,7 +216,7 @@ def main():
         for name, kid, gl in (("csr_wave", rx.KERNEL_CSR_WAVE, 0), ("sym_wave", rx.KERNEL_SYM_WAVE, 0),
                               ("sym_group1", rx.KERNEL_SYM_GROUP, 1), ("sym_group2", rx.KERNEL_SYM_GROUP, 2),
                               ("sym_group4", rx.KERNEL_SYM_GROUP, 4), ("sym_group8", rx.KERNEL_SYM_GROUP, 8),
-                              ("sym_group16", rx.KERNEL_SYM_GROUP, 16), ("sym_pack8", rx.KERNEL_SYM_PACK, 8), ("sym_pack12", rx.KERNEL_SYM_PACK, 12),
+                              ("sym_group16", rx.KERNEL_SYM_GROUP, 16), ("sym_pack2", rx.KERNEL_SYM_PACK, 2), ("sym_pack4", rx.KERNEL_SYM_PACK, 4), ("sym_pack8", rx.KERNEL_SYM_PACK, 8), ("sym_pack12", rx.KERNEL_SYM_PACK, 12),
                               ("sym_pack16", rx.KERNEL_SYM_PACK, 16), ("sym_pack20", rx.KERNEL_SYM_PACK, 20),
                               ("sym_pack24", rx.KERNEL_SYM_PACK, 24), ("sym_pack32", rx.KERNEL_SYM_PACK, 32)):
             p2 = rx.Plan(nfa, ns, sl, mode=rx.MODE_FULL, kernel=kid, device=local, stream=stream, events_cap=1 << 22,

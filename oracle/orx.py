@@ -20,7 +20,7 @@ class Event(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("n_passes", C.c_uint64), ("n_events", C.c_uint64), ("sum_active", C.c_uint64),
-                ("sum_edges", C.c_uint64), ("alg_bytes", C.c_uint64)]
+                ("sum_edges", C.c_uint64), ("alg_bytes", C.c_uint64), ("max_active", C.c_uint64)]
 
 
 class TbResult(C.Structure):
@@ -136,7 +136,7 @@ def match_batch(words, size, data, mode=MODE_FULL, nthreads=0, init_active=None,
     return dict(events=ev[:n], n_events=nev.value, match_count=mc, match_count_total=tot, anymatch=am,
                 final_active=fin, threads=thr.value,
                 stats=dict(n_passes=st.n_passes, n_events=st.n_events, sum_active=st.sum_active,
-                           sum_edges=st.sum_edges, alg_bytes=st.alg_bytes))
+                           sum_edges=st.sum_edges, alg_bytes=st.alg_bytes, max_active=st.max_active))
 
 
 def tb_cycle(words, size, lo, hi, m_stop, bram_latency=1, skip_idle=True, max_cycles=0, events_cap=1 << 16):

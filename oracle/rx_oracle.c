@@ -158,13 +158,14 @@ int orx_match_stream(const uint32_t* W, uint32_t size, const uint8_t* bytes, siz
 
   const uint64_t n_passes = orx_passes(n, mode);
   uint64_t nev = n_events_io ? *n_events_io : 0;
-  uint64_t sum_active = 0, sum_edges = 0, ev_local = 0;
+  uint64_t sum_active = 0, sum_edges = 0, ev_local = 0, max_active = 0;
   if (anymatch) memset(anymatch, 0, ((n_passes + 31) / 32) * sizeof(uint32_t));
   int rc = 0;
 
   for (uint64_t k = 0; k < n_passes; k++) {
     const int has_byte = k < n; /* pass N of FULL mode only checks accepts */
     const uint32_t c = has_byte ? bytes[k] : 0;
+    const uint64_t active_before = sum_active;
     for (size_t wi = 0; wi < nw; wi++) {       /* FPGA.v:158/744: scan i upward            */
       uint64_t x = cur[wi];
       while (x) {
@@ -191,6 +192,7 @@ int orx_match_stream(const uint32_t* W, uint32_t size, const uint8_t* bytes, siz
         }
       }
     }
+    if (sum_active - active_before > max_active) max_active = sum_active - active_before;
     if (has_byte) {                              /* FPGA.v:733-737 current<=next; next<=0   */
       uint64_t* t = cur; cur = nxt; nxt = t;
       memset(nxt, 0, nw * sizeof(uint64_t));
@@ -204,6 +206,7 @@ done:
     stats->n_events += ev_local;
     stats->sum_active += sum_active;
     stats->sum_edges += sum_edges;
+    if (max_active > stats->max_active) stats->max_active = max_active;
   }
   free(cur < nxt ? cur : nxt);
   return rc;
@@ -226,7 +229,7 @@ static void* batch_worker(void* arg) {
     if (mc) memset(mc, 0, j->size * sizeof(uint32_t));
     for (;;) {
       uint64_t nev = before;
-      orx_stats st = {0, 0, 0, 0, 0};
+      orx_stats st = {0, 0, 0, 0, 0, 0};
       int rc = orx_match_stream(j->W, j->size, j->bytes + s * j->stride, j->stream_len, j->mode, (uint32_t)s,
                                 j->init_active ? j->init_active + s * nw : NULL,
                                 NULL, j->ev, j->ev_cap, &nev,
@@ -243,6 +246,7 @@ static void* batch_worker(void* arg) {
       j->ev_n = nev;
       j->st.n_passes = st.n_passes;
       j->st.n_events += st.n_events; j->st.sum_active += st.sum_active; j->st.sum_edges += st.sum_edges;
+      if (st.max_active > j->st.max_active) j->st.max_active = st.max_active;
       break;
     }
     /* Blk_Mem_tb's counters (testbench_BLK_Mem.sv:61-69): one increment per pulse */
@@ -282,7 +286,7 @@ int orx_match_batch(const uint32_t* W, uint32_t size, const uint8_t* bytes, size
   }
   int rc = 0;
   uint64_t total = 0;
-  orx_stats st = {0, 0, 0, 0, 0};
+  orx_stats st = {0, 0, 0, 0, 0, 0};
   if (match_count_total) memset(match_count_total, 0, size * sizeof(uint64_t));
   for (int t = 0; t < nthreads; t++) {
     if (nthreads > 1) pthread_join(th[t], NULL);
@@ -294,6 +298,7 @@ int orx_match_batch(const uint32_t* W, uint32_t size, const uint8_t* bytes, size
     }
     st.n_passes = j->st.n_passes ? j->st.n_passes : st.n_passes;
     st.n_events += j->st.n_events; st.sum_active += j->st.sum_active; st.sum_edges += j->st.sum_edges;
+    if (j->st.max_active > st.max_active) st.max_active = j->st.max_active;
     if (match_count_total) for (uint32_t i = 0; i < size; i++) match_count_total[i] += mct[t][i];
     free(j->ev); free(mct[t]);
   }

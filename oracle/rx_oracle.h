@@ -32,6 +32,7 @@ typedef struct orx_stats {
   uint64_t sum_active; /* sum_k |S_k| over all streams */
   uint64_t sum_edges;  /* sum_k sum_{i in S_k} deg(i) */
   uint64_t alg_bytes;  /* SURVEY §8(d) accounting, see orx_alg_bytes() */
+  uint64_t max_active; /* largest |S_k| seen in any pass of any stream */
 } orx_stats;
 
 /* ---- file formats (Block_Mem .coe, Simulation .mem) ---- */

@@ -368,11 +368,12 @@ __global__ void __launch_bounds__(256) rx_sym_wave_kernel(const RxParams p) {
         // rows with several targets on this byte: the whole wave expands one list at a time, 64 targets
         // per step (coalesced), instead of one lane walking it alone
         uint64_t mo = wballot(ent & RXE_OVF);
+        const uint32_t mycnt = (ent & RXE_OVF) ? ovf[ent & RXE_TGT_MASK] : 0u;  // all list lengths in one gather
         while (mo) {
           const uint32_t src = (uint32_t)__builtin_ctzll(mo);
           mo &= mo - 1;
           const uint32_t off = bcast(ent & RXE_TGT_MASK, src);
-          const uint32_t cnt = ovf[off];
+          const uint32_t cnt = bcast(mycnt, src);
           for (uint32_t j0 = 0; j0 < cnt; j0 += 64u) {
             const bool act = j0 + lane < cnt;
             const uint32_t t = act ? ovf[off + 1u + j0 + lane] : 0u;
@@ -928,13 +929,15 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       }
       // rows with several targets on this byte: the wave expands one such list at a time, 64 targets per step
       uint64_t mo = wballot(x & RXE_OVF);
+      uint32_t mycnt = 0;
+      if (mo && (x & RXE_OVF)) mycnt = ovf[x & RXE_TGT_MASK];  // all list lengths in one gather
       while (mo) {
         const uint32_t src = (uint32_t)__builtin_ctzll(mo);
         mo &= mo - 1;
         const uint32_t off = bcast(x & RXE_TGT_MASK, src);
         const uint32_t osid = bcast(sid, src);
         uint32_t* oreg = sreg0 + osid * L::STRIDE;
-        const uint32_t cnt = ovf[off];
+        const uint32_t cnt = bcast(mycnt, src);
         for (uint32_t q0 = 0; q0 < cnt; q0 += 64u) {
           const bool act = q0 + lane < cnt;
           const uint32_t w = act ? ovf[off + 1u + q0 + lane] : 0u;
@@ -1030,7 +1033,7 @@ int rx_pick_launch(uint32_t kernel, uint32_t size, uint32_t n_streams, int cu_co
   cfg->grid_blocks = blocks ? blocks : 1;
   if (kernel == RX_KERNEL_SYM_PACK) {
     const uint32_t gl = cfg->group_lanes;  // here: streams per wavefront
-    if (gl != 8 && gl != 12 && gl != 16 && gl != 20 && gl != 24 && gl != 32) cfg->group_lanes = 16;
+    if (gl != 2 && gl != 4 && gl != 8 && gl != 12 && gl != 16 && gl != 20 && gl != 24 && gl != 32) cfg->group_lanes = 16;
   }
   if (kernel == RX_KERNEL_SYM_GROUP) {
     const uint32_t gl = cfg->group_lanes;
@@ -1091,7 +1094,9 @@ int rx_launch(const RxParams& p, const RxLaunchCfg& cfg, void* hip_stream) {
     case RX_KERNEL_SYM_GROUP: {
       int e;
       if (cfg.kernel == RX_KERNEL_SYM_PACK) {
-        if (cfg.group_lanes == 8) e = launch_pack<8>(p, cfg, s);
+        if (cfg.group_lanes == 2) e = launch_pack<2>(p, cfg, s);
+        else if (cfg.group_lanes == 4) e = launch_pack<4>(p, cfg, s);
+        else if (cfg.group_lanes == 8) e = launch_pack<8>(p, cfg, s);
         else if (cfg.group_lanes == 12) e = launch_pack<12>(p, cfg, s);
         else if (cfg.group_lanes == 20) e = launch_pack<20>(p, cfg, s);
         else if (cfg.group_lanes == 24) e = launch_pack<24>(p, cfg, s);
