@@ -110,7 +110,8 @@ enum {
   RX_KERNEL_AUTO = 0,     /* probe, then choose: on the first launch for a batch the plan runs the pack
                              kernel's statistics build over a corner of it (<= 512 streams x <= 1 KB; this
                              synchronises the stream once) and picks RX_KERNEL_SYM_PACK for small active
-                             sets (<= 6 states per stream-byte), RX_KERNEL_SYM_WAVE otherwise          */
+                             sets (<= 6 states per stream-byte; streams per wavefront ~ 37 / that number),
+                             RX_KERNEL_SYM_WAVE otherwise                                              */
   RX_KERNEL_CSR_WAVE = 1, /* wavefront-per-stream over the state-major CSR exactly as loaded         */
   RX_KERNEL_SYM_WAVE = 2, /* wavefront-per-stream over the per-(state,symbol) slice index            */
   RX_KERNEL_SYM_GROUP = 3, /* G lanes per stream (64/G streams per wavefront), slice index;

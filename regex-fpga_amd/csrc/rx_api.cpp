@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -249,6 +250,7 @@ struct rx_plan {
   bool have_input = false, launched = false;
   bool auto_decided = false;   // RX_KERNEL_AUTO: the probe has run for the current batch
   uint32_t auto_kernel = RX_KERNEL_SYM_PACK;
+  uint32_t auto_lanes = 16;    // streams per wavefront chosen for the pack kernel
   double probe_active = 0;     // active states per stream-byte seen by the probe
   RxParams params{};
   RxLaunchCfg cfg{};
@@ -440,6 +442,7 @@ static int ensure_spill_area(rx_plan* p, RxParams& a) {
 // bytes, no outputs), then: small active sets -> pack kernel, larger ones -> wavefront-per-stream slice kernel.
 static int auto_probe(rx_plan* p) {
   p->auto_kernel = RX_KERNEL_SYM_PACK;
+  p->auto_lanes = 16;
   p->probe_active = 0;
   if (p->n_streams * p->stream_len < (256u << 10)) return RX_OK;  // tiny batch: not worth a probe
   RxParams a;
@@ -463,7 +466,21 @@ static int auto_probe(rx_plan* p) {
   const double units = (double)a.n_streams * std::max<uint32_t>(a.stream_len, 1);
   p->probe_active = (double)cnt[1] / units;
   const double spilled = (double)cnt[3] / a.n_streams;
-  if (p->probe_active > 6.0 || spilled > 0.02) p->auto_kernel = RX_KERNEL_SYM_WAVE;
+  if (p->probe_active > 6.0 || spilled > 0.02) {
+    p->auto_kernel = RX_KERNEL_SYM_WAVE;
+  } else {
+    // the pack kernel is fastest when one pass of a wavefront is ONE iteration with ~37 of the 64 lanes busy:
+    // streams per wavefront ~ 37 / (active states per stream)   (snort_16: T 2.3 -> 16, U 1.15 -> 32)
+    static const uint32_t choices[] = {8, 12, 16, 20, 24, 32};
+    const double want = 37.0 / std::max(p->probe_active, 0.5);
+    uint32_t best = 16;
+    double bd = 1e9;
+    for (uint32_t c : choices) {
+      const double d = std::abs((double)c - want);
+      if (d < bd) { bd = d; best = c; }
+    }
+    p->auto_lanes = best;
+  }
   return RX_OK;
 }
 
@@ -490,6 +507,7 @@ extern "C" int rx_plan_launch(rx_plan* p) {
   a.anymatch_stride = (uint32_t)p->am_stride;
   a.final_active = p->want_final ? p->d_final : nullptr;
   uint32_t kernel = p->opts.kernel;
+  uint32_t auto_lanes = 0;
   const bool pair = p->opts.collect_stats == 2;
   if (pair) {  // the testbench's clock count needs both streams of a pair in one wavefront: pack kernel only
     if ((kernel != RX_KERNEL_AUTO && kernel != RX_KERNEL_SYM_PACK) || (p->n_streams & 1) || p->have_init) return RX_EINVAL;
@@ -502,11 +520,12 @@ extern "C" int rx_plan_launch(rx_plan* p) {
       p->auto_decided = true;
     }
     kernel = p->auto_kernel;
+    if (p->opts.group_lanes == 0 && kernel == RX_KERNEL_SYM_PACK) auto_lanes = p->auto_lanes;
   }
   // a caller-supplied start set is a bitmask row: that is the wave kernel's dense form
   if (p->have_init && (kernel == RX_KERNEL_AUTO || kernel == RX_KERNEL_SYM_GROUP || kernel == RX_KERNEL_SYM_PACK))
     kernel = RX_KERNEL_SYM_WAVE;
-  p->cfg.group_lanes = p->opts.group_lanes;
+  p->cfg.group_lanes = auto_lanes ? auto_lanes : p->opts.group_lanes;
   rc = rx_pick_launch(kernel, h.size, a.n_streams, p->tab.cu_count, p->tab.lds_per_cu, &a, &p->cfg);
   if (rc) return rc;
   p->cfg.stats = p->opts.collect_stats != 0;

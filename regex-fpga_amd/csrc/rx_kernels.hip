@@ -927,22 +927,24 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
         resolve(m0, e);
         resolve(m1, t1);
       }
-      // rows with several targets on this byte: the wave expands one such list at a time, 64 targets per step
+      // rows with several targets on this byte (rare on snort_16, every pass on l7): the wave expands one such
+      // list at a time, 64 targets per step, list lengths gathered up front
       uint64_t mo = wballot(x & RXE_OVF);
-      uint32_t mycnt = 0;
-      if (mo && (x & RXE_OVF)) mycnt = ovf[x & RXE_TGT_MASK];  // all list lengths in one gather
-      while (mo) {
-        const uint32_t src = (uint32_t)__builtin_ctzll(mo);
-        mo &= mo - 1;
-        const uint32_t off = bcast(x & RXE_TGT_MASK, src);
-        const uint32_t osid = bcast(sid, src);
-        uint32_t* oreg = sreg0 + osid * L::STRIDE;
-        const uint32_t cnt = bcast(mycnt, src);
-        for (uint32_t q0 = 0; q0 < cnt; q0 += 64u) {
-          const bool act = q0 + lane < cnt;
-          const uint32_t w = act ? ovf[off + 1u + q0 + lane] : 0u;
-          insert(act, (w & (RXE_TGT_MASK | RXE_ACCEPT)) | (osid << SID_SHIFT), oreg);
-        }
+      if (__builtin_expect(mo != 0, 0)) {
+        const uint32_t mycnt = (x & RXE_OVF) ? ovf[x & RXE_TGT_MASK] : 0u;
+        do {
+          const uint32_t src = (uint32_t)__builtin_ctzll(mo);
+          mo &= mo - 1;
+          const uint32_t off = bcast(x & RXE_TGT_MASK, src);
+          const uint32_t osid = bcast(sid, src);
+          uint32_t* oreg = sreg0 + osid * L::STRIDE;
+          const uint32_t cnt = bcast(mycnt, src);
+          for (uint32_t q0 = 0; q0 < cnt; q0 += 64u) {
+            const bool act = q0 + lane < cnt;
+            const uint32_t w = act ? ovf[off + 1u + q0 + lane] : 0u;
+            insert(act, (w & (RXE_TGT_MASK | RXE_ACCEPT)) | (osid << SID_SHIFT), oreg);
+          }
+        } while (mo);
       }
     }
 

@@ -66,7 +66,8 @@ _lib = None
 
 
 def lib_path():
-    return os.path.join(_HERE, "librxmatch.so")
+    """In-tree library; RX_LIBRARY_PATH overrides it (A/B runs of two builds in one session)."""
+    return os.environ.get("RX_LIBRARY_PATH") or os.path.join(_HERE, "librxmatch.so")
 
 
 def _share_hip_runtime_with_torch():
