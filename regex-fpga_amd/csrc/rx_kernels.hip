@@ -910,9 +910,11 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       const uint32_t t1 = (x & (RXE_TGT_MASK | RXE_ACCEPT)) | (sid << SID_SHIFT);
       const uint32_t h0 = e & HMASK, h1 = x & HMASK;
       const uint32_t bt0 = 1u << (h0 & 31u), bt1 = 1u << (h1 & 31u);
-      uint32_t o0 = 0, o1 = 0;
-      if (p0) o0 = atomicOr(&sreg[fnext_off + (h0 >> 5)], bt0);
-      if (p1) o1 = atomicOr(&sreg[fnext_off + (h1 >> 5)], bt1);
+      // both filter atomics are issued by every lane, back to back, with one wait: a lane without a candidate
+      // ORs 0 into its own list slot (a no-op on a private address) instead of sitting out in a branch
+      uint32_t* const idle = clist + lane;
+      const uint32_t o0 = atomicOr(p0 ? &sreg[fnext_off + (h0 >> 5)] : idle, p0 ? bt0 : 0u);
+      const uint32_t o1 = atomicOr(p1 ? &sreg[fnext_off + (h1 >> 5)] : idle, p1 ? bt1 : 0u);
       const bool f0 = p0 && !(o0 & bt0), f1 = p1 && !(o1 & bt1);
       const bool m0 = p0 && (o0 & bt0), m1 = p1 && (o1 & bt1);
       const uint64_t mf0 = wballot(f0), mf1 = wballot(f1);
