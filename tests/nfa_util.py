@@ -56,3 +56,17 @@ def blowup_nfa(width):
         e.append((s, 0x42, acc))
         e.append((s, 0x43, s))
     return build_words(size, e), size
+
+
+def late_blowup_nfa(width):
+    """Unanchored "ab" (accept state 3) next to a trap: byte 'Z' seen by the `.*` state 1 activates `width`
+    states that keep each other alive on 'Y' and all fall into accept state 3 on 'B'.  A stream can therefore
+    produce accept pulses, THEN outgrow any fixed list (hand-off), THEN produce more pulses."""
+    size = 4 + width
+    e = [(0, c, 1) for c in range(256)] + [(1, c, 1) for c in range(256)]
+    e += [(0, ord("a"), 2), (1, ord("a"), 2), (2, ord("b"), 3)]
+    wide = list(range(4, 4 + width))
+    e += [(0, ord("Z"), t) for t in wide] + [(1, ord("Z"), t) for t in wide]
+    for i, s in enumerate(wide):
+        e += [(s, ord("Y"), s), (s, ord("Y"), wide[(i + 1) % width]), (s, ord("B"), 3)]
+    return build_words(size, e), size

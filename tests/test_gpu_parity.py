@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN
-from nfa_util import blowup_nfa, build_words, kat_ab, random_nfa
+from nfa_util import blowup_nfa, build_words, kat_ab, late_blowup_nfa, random_nfa
 
 pytestmark = pytest.mark.gpu
 G = json.load(open(os.path.join(GOLDEN, "golden.json")))
@@ -200,6 +200,28 @@ def test_active_set_larger_than_list_capacity(rx, orx, kernels):
     for kern in kernels:
         got = rx.match(nfa, rows, **kern, want_match_count=True, collect_stats=True)
         check_equal(rx, orx, got, ref, ("blowup", kern))
+
+
+def test_handoff_in_the_middle_of_a_stream(rx, orx, kernels):
+    """Accept pulses before AND after the pass at which a stream outgrows the group / pack kernel's list: the
+    hand-off to the wave kernel must keep the earlier pulses, the partial any-match word, the pinned state and
+    the statistics, for streams that blow up at different passes (or never) inside one wavefront."""
+    W, size = late_blowup_nfa(220)
+    nfa = rx.Nfa.from_words(W)
+    base = b"xabxab..abYab"
+    rows = np.zeros((40, 96), np.uint8)
+    for s in range(40):
+        txt = bytearray((base * 10)[:96])
+        if s % 3 != 2:                       # every third stream never blows up
+            at = 7 + (s * 5) % 60
+            txt[at:at + 6] = b"ZYYBab"
+        rows[s] = np.frombuffer(bytes(txt), np.uint8)
+    for mode in (rx.MODE_FULL, rx.MODE_TB_COMPAT):
+        ref = orx.match_batch(W, size, rows, mode=mode, want_match_count=True)
+        assert ref["stats"]["max_active"] > 200 and ref["n_events"] > 100
+        for kern in kernels:
+            got = rx.match(nfa, rows, mode=mode, want_match_count=True, collect_stats=True, **kern)
+            check_equal(rx, orx, got, ref, ("late handoff", mode, kern))
 
 
 def test_random_automata(rx, orx, kernels):
