@@ -331,3 +331,16 @@ def test_report_cli(rx, orx, automata, traces):
     c = orx.tb_cycle(W, size, traces[("l7", "lo")][:N + 1], traces[("l7", "hi")][:N + 1], N, skip_idle=True)
     assert out.rstrip("\n") == rx.testbench.format_report(c["match_count"], c["match_count_2"], c["total_cycles"],
                                                           10 * c["total_cycles"] + 22)
+
+
+def test_plain_c_caller(rx, tmp_path):
+    """A C99 program that only includes include/rxmatch.h and links librxmatch.so runs the App. B.4 known answer."""
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "abi_kat")
+    libdir = os.path.dirname(rx.lib_path())
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "native", "abi_kat.c"), "-o", exe, "-L", libdir, "-lrxmatch",
+                           f"-Wl,-rpath,{libdir}"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "abi_kat ok" in out.stdout, out.stdout + out.stderr
