@@ -344,3 +344,16 @@ def test_plain_c_caller(rx, tmp_path):
                            f"-Wl,-rpath,{libdir}"])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "abi_kat ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_randomized_differential_short(rx, orx):
+    """A slice of tools/fuzz_gpu.py: seeded random automata (raw tables, blow-ups, compiled regexes) x random inputs,
+    six randomly chosen kernel variants per case, everything compared with the oracle."""
+    import importlib.util
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("fuzz_gpu", os.path.join(ROOT, "tools", "fuzz_gpu.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    for trial in range(400):
+        err = fz.one_case(np.random.default_rng([7, trial]), trial)
+        assert err is None, err
