@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--stream-len", type=int, default=1024)
     ap.add_argument("--workload", choices=["T", "U", "R"], default="T",
                     help="T trace windows (headline), U uniform bytes, R synthetic ~10k-state ruleset stand-in")
-    ap.add_argument("--kernel", default="auto", choices=["auto", "csr_wave", "sym_wave", "sym_group", "sym_pack"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "csr_wave", "sym_wave", "sym_group", "sym_pack", "dfa"])
     ap.add_argument("--group-lanes", type=int, default=0)
     ap.add_argument("--cpu-threads", type=int, default=16, help="cap on oracle threads (box share: 16 per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -99,7 +99,7 @@ def main():
 
     wl = rx.workloads
     kern = {"auto": rx.KERNEL_AUTO, "csr_wave": rx.KERNEL_CSR_WAVE, "sym_wave": rx.KERNEL_SYM_WAVE,
-            "sym_group": rx.KERNEL_SYM_GROUP, "sym_pack": rx.KERNEL_SYM_PACK}[a.kernel]
+            "sym_group": rx.KERNEL_SYM_GROUP, "sym_pack": rx.KERNEL_SYM_PACK, "dfa": rx.KERNEL_DFA}[a.kernel]
     if a.workload == "R":  # BASELINE configs[4] stand-in: synthetic ruleset compiled by rx_compile_patterns
         traces = wl.synthetic_ruleset()
         nfa = rx.Nfa.compile(traces)
@@ -218,7 +218,8 @@ def main():
                               ("sym_group4", rx.KERNEL_SYM_GROUP, 4), ("sym_group8", rx.KERNEL_SYM_GROUP, 8),
                               ("sym_group16", rx.KERNEL_SYM_GROUP, 16), ("sym_pack2", rx.KERNEL_SYM_PACK, 2), ("sym_pack4", rx.KERNEL_SYM_PACK, 4), ("sym_pack8", rx.KERNEL_SYM_PACK, 8), ("sym_pack12", rx.KERNEL_SYM_PACK, 12),
                               ("sym_pack16", rx.KERNEL_SYM_PACK, 16), ("sym_pack20", rx.KERNEL_SYM_PACK, 20),
-                              ("sym_pack24", rx.KERNEL_SYM_PACK, 24), ("sym_pack32", rx.KERNEL_SYM_PACK, 32)):
+                              ("sym_pack24", rx.KERNEL_SYM_PACK, 24), ("sym_pack32", rx.KERNEL_SYM_PACK, 32),
+                              ("dfa_warm", rx.KERNEL_DFA, 0)):
             p2 = rx.Plan(nfa, ns, sl, mode=rx.MODE_FULL, kernel=kid, device=local, stream=stream, events_cap=1 << 22,
                          group_lanes=gl)
             p2.set_device_input(d_rows.data_ptr(), ns, sl, sl, keepalive=d_rows)

@@ -98,6 +98,12 @@ int rx_nfa_accept_pattern(const rx_nfa* nfa, uint32_t state, int32_t* pattern_in
  * (radix 16, one 128-bit line per row of text) so it can initialise the reference's ROM. */
 int rx_nfa_save_coe(const rx_nfa* nfa, const char* path);
 
+/* ---- lazy-DFA cache of RX_KERNEL_DFA ------------------------------------------------------- */
+/* Number of DFA states / transitions built so far on `device` (0/0 before the first DFA launch). */
+int rx_nfa_dfa_info(const rx_nfa* nfa, int device, uint64_t* n_states, uint64_t* n_transitions);
+/* Forget everything built so far on `device` (the next DFA launch starts cold). */
+int rx_nfa_dfa_reset(const rx_nfa* nfa, int device);
+
 /* ---- traces ----------------------------------------------------------------------------- */
 /* $readmemh text (one 1-2 digit hex byte per line) -> malloc'ed byte array; release with rx_free. */
 int rx_trace_load_mem(const char* path, uint8_t** bytes, size_t* n);
@@ -120,6 +126,11 @@ enum {
   RX_KERNEL_SYM_PACK = 4  /* S streams per wavefront, the 64 lanes assigned dynamically to one wave-wide
                              list of (stream,state) entries; rx_opts.group_lanes = S (8/12/16/20/24/32,
                              default 16); same hand-off to RX_KERNEL_SYM_WAVE                         */
+  ,
+  RX_KERNEL_DFA = 5       /* opt-in: lazy DFA, one LANE per stream and one table lookup per byte; the subset-
+                             construction cache lives in HBM per automaton and device, is grown on the device
+                             and persists across launches (rx_nfa_dfa_reset clears it); sets it cannot hold
+                             are handed to RX_KERNEL_SYM_WAVE.  Never chosen by RX_KERNEL_AUTO.             */
 };
 
 typedef struct rx_opts {

@@ -63,6 +63,9 @@ struct DevTables {
   uint32_t* accept_bits = nullptr;
   uint32_t* symidx_c = nullptr;
   uint32_t* byte_class = nullptr;
+  // lazy-DFA cache (allocated by the first RX_KERNEL_DFA launch)
+  uint32_t *dfa_trans = nullptr, *dfa_pool = nullptr, *dfa_hash = nullptr, *dfa_hdr = nullptr;
+  uint32_t dfa_pool_chunks = 0, dfa_hash_mask = 0;
   int cu_count = 0;
   size_t lds_per_cu = 0;
 };
@@ -150,6 +153,10 @@ extern "C" void rx_nfa_free(rx_nfa* nfa) {
     (void)hipFree(kv.second.accept_bits);
     (void)hipFree(kv.second.symidx_c);
     (void)hipFree(kv.second.byte_class);
+    (void)hipFree(kv.second.dfa_trans);
+    (void)hipFree(kv.second.dfa_pool);
+    (void)hipFree(kv.second.dfa_hash);
+    (void)hipFree(kv.second.dfa_hdr);
   }
   if (have_prev) (void)hipSetDevice(prev);
   delete nfa;
@@ -220,6 +227,77 @@ static int get_dev_tables(const rx_nfa* cnfa, int device, DevTables* out) {
   nfa->dev[device] = t;
   *out = t;
   return RX_OK;
+}
+
+// ---- lazy-DFA cache -----------------------------------------------------------------------------
+static int dfa_init_tables(const rx_nfa* nfa, DevTables& t) {
+  const RxHostNfa& h = nfa->h;
+  HIPCHK(hipMemset(t.dfa_trans, 0, (size_t)t.dfa_pool_chunks * h.n_classes * sizeof(uint32_t)));
+  HIPCHK(hipMemset(t.dfa_pool, 0, (size_t)t.dfa_pool_chunks * 32 * sizeof(uint32_t)));
+  HIPCHK(hipMemset(t.dfa_hash, 0, ((size_t)t.dfa_hash_mask + 1) * sizeof(uint32_t)));
+  // chunk 0 is never used (0 = "unknown"); chunk 1 = the reset set {state 0} (Design/FPGA.v:134-147)
+  const bool acc0 = (h.accept_bits[0] & 1u) != 0;
+  uint32_t first[32] = {0};
+  first[0] = 1;
+  first[1] = h.row_ptr()[1] - h.row_ptr()[0];
+  first[2] = acc0 ? 1u : 0u;
+  first[DFA_HDR_WORDS] = 0u | (acc0 ? RXE_ACCEPT : 0u);
+  HIPCHK(hipMemcpy(t.dfa_pool + 32, first, sizeof(first), hipMemcpyHostToDevice));
+  const uint32_t hdr[4] = {0, 2, 1, 0};  // next free chunk = 2, one state so far
+  HIPCHK(hipMemcpy(t.dfa_hdr, hdr, sizeof(hdr), hipMemcpyHostToDevice));
+  return RX_OK;
+}
+
+static int ensure_dfa_tables(const rx_nfa* cnfa, int device, DevTables* out) {
+  rx_nfa* nfa = const_cast<rx_nfa*>(cnfa);
+  std::lock_guard<std::mutex> lk(nfa->mu);
+  DevTables& t = nfa->dev[device];
+  if (!t.dfa_trans) {
+    t.dfa_pool_chunks = 1u << 18;  // 262 144 chunks of 128 B: up to that many DFA states (32 MB)
+    t.dfa_hash_mask = (1u << 19) - 1;
+    HIPCHK(hipMalloc((void**)&t.dfa_trans, (size_t)t.dfa_pool_chunks * nfa->h.n_classes * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void**)&t.dfa_pool, (size_t)t.dfa_pool_chunks * 32 * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void**)&t.dfa_hash, ((size_t)t.dfa_hash_mask + 1) * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void**)&t.dfa_hdr, 4 * sizeof(uint32_t)));
+    int rc = dfa_init_tables(nfa, t);
+    if (rc) return rc;
+  }
+  *out = t;
+  return RX_OK;
+}
+
+extern "C" int rx_nfa_dfa_info(const rx_nfa* cnfa, int device, uint64_t* n_states, uint64_t* n_transitions) {
+  if (!cnfa) return RX_EINVAL;
+  rx_nfa* nfa = const_cast<rx_nfa*>(cnfa);
+  std::lock_guard<std::mutex> lk(nfa->mu);
+  if (n_states) *n_states = 0;
+  if (n_transitions) *n_transitions = 0;
+  auto it = nfa->dev.find(device);
+  if (it == nfa->dev.end() || !it->second.dfa_hdr) return RX_OK;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  HIPCHK(hipSetDevice(device));
+  uint32_t hdr[4] = {0, 0, 0, 0};
+  HIPCHK(hipMemcpy(hdr, it->second.dfa_hdr, sizeof(hdr), hipMemcpyDeviceToHost));
+  if (prev >= 0) (void)hipSetDevice(prev);
+  if (n_states) *n_states = hdr[2];
+  if (n_transitions) *n_transitions = hdr[3];
+  return RX_OK;
+}
+
+extern "C" int rx_nfa_dfa_reset(const rx_nfa* cnfa, int device) {
+  if (!cnfa) return RX_EINVAL;
+  rx_nfa* nfa = const_cast<rx_nfa*>(cnfa);
+  std::lock_guard<std::mutex> lk(nfa->mu);
+  auto it = nfa->dev.find(device);
+  if (it == nfa->dev.end() || !it->second.dfa_trans) return RX_OK;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(hipDeviceSynchronize());
+  int rc = dfa_init_tables(nfa, it->second);
+  if (prev >= 0) (void)hipSetDevice(prev);
+  return rc;
 }
 
 // ---- plan -----------------------------------------------------------------------------------------
@@ -523,14 +601,27 @@ extern "C" int rx_plan_launch(rx_plan* p) {
     if (p->opts.group_lanes == 0 && kernel == RX_KERNEL_SYM_PACK) auto_lanes = p->auto_lanes;
   }
   // a caller-supplied start set is a bitmask row: that is the wave kernel's dense form
-  if (p->have_init && (kernel == RX_KERNEL_AUTO || kernel == RX_KERNEL_SYM_GROUP || kernel == RX_KERNEL_SYM_PACK))
+  if (p->have_init && (kernel == RX_KERNEL_AUTO || kernel == RX_KERNEL_SYM_GROUP || kernel == RX_KERNEL_SYM_PACK ||
+                       kernel == RX_KERNEL_DFA))
     kernel = RX_KERNEL_SYM_WAVE;
   p->cfg.group_lanes = auto_lanes ? auto_lanes : p->opts.group_lanes;
   rc = rx_pick_launch(kernel, h.size, a.n_streams, p->tab.cu_count, p->tab.lds_per_cu, &a, &p->cfg);
   if (rc) return rc;
   p->cfg.stats = p->opts.collect_stats != 0;
-  const bool two_tier = p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK;
+  const bool two_tier = p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK ||
+                        p->cfg.kernel == RX_KERNEL_DFA;
   if (two_tier && (rc = ensure_spill_area(p, a))) return rc;
+  if (p->cfg.kernel == RX_KERNEL_DFA) {
+    if (pair) return RX_EINVAL;
+    DevTables t;
+    if ((rc = ensure_dfa_tables(p->nfa, p->device, &t))) return rc;
+    a.dfa_trans = t.dfa_trans;
+    a.dfa_pool = t.dfa_pool;
+    a.dfa_hash = t.dfa_hash;
+    a.dfa_hdr = t.dfa_hdr;
+    a.dfa_pool_chunks = t.dfa_pool_chunks;
+    a.dfa_hash_mask = t.dfa_hash_mask;
+  }
 
   HIPCHK(hipMemsetAsync(p->d_counters, 0, 8 * sizeof(unsigned long long), p->stream));
   HIPCHK(hipMemsetAsync(p->d_mct, 0, (size_t)h.size * sizeof(unsigned long long), p->stream));
@@ -610,7 +701,8 @@ extern "C" int rx_plan_download(rx_plan* p, rx_result* res) {
   st.n_events = cnt[0];
   st.kernel_ms = p->last_ms;
   st.kernel_used = p->cfg.kernel;
-  st.n_launches = (p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK) ? 2 : 1;
+  st.n_launches = (p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK ||
+                   p->cfg.kernel == RX_KERNEL_DFA) ? 2 : 1;
   if (p->cfg.stats) {
     st.sum_active = cnt[1];
     st.sum_edges = cnt[2];

@@ -71,9 +71,20 @@ struct RxParams {
   uint32_t pin_state;               // group kernel: pinned state id, 0xFFFFFFFF = none
   uint32_t pin_degree;              // its row length (for the algorithmic-byte statistics)
   uint32_t pair_cycles;             // stats build: also sum the FPGA clock cost of stream pairs (2q, 2q+1)
+  // lazy DFA cache (rx_dfa_kernel): persistent per automaton and device, grown on the device
+  uint32_t* dfa_trans;              // [pool_chunks][n_classes]: 0 unknown, DFA_EXIT, else next id | DFA_ACC
+  uint32_t* dfa_pool;               // [pool_chunks][32]: state id = index of its first 32-word chunk
+  uint32_t* dfa_hash;               // [hash_mask+1] open-addressing table of ids
+  uint32_t* dfa_hdr;                // [0] unused [1] next free chunk [2] states created [3] transitions built
+  uint32_t dfa_pool_chunks;
+  uint32_t dfa_hash_mask;
 };
 
 static constexpr uint32_t RX_GROUP_CAP = 24;     // group kernel: active-list capacity per stream
+static constexpr uint32_t DFA_ACC = 0x80000000u;   // transition value: the target set contains an accept state
+static constexpr uint32_t DFA_EXIT = 0xFFFFFFFFu;  // transition value: target set not representable -> NFA kernel
+static constexpr uint32_t DFA_MAXM = 61;           // members per DFA state (two 32-word chunks minus header)
+static constexpr uint32_t DFA_HDR_WORDS = 3;       // chunk header: count, sum of degrees, has-accept
 static constexpr uint32_t RX_PACK_CAP = 192;      // pack kernel: wave-wide active-list capacity (entries)
 static constexpr uint32_t RX_GROUP_FILTER_WORDS = 32;  // 1024-bit hashed dedup filter per stream
 

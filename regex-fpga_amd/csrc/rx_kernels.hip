@@ -1010,6 +1010,286 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
   }
 }
 
+// =================================================================================================
+// Kernel 5: lazy DFA — one LANE per stream, one table lookup per input byte
+// =================================================================================================
+// Every NFA kernel above pays, per stream and byte, for each active state separately.  Here a stream carries ONE
+// id that names its whole active SET (subset construction done lazily, as RE2/Hyperscan do on CPUs): a pass is
+//     id <- dfa_trans[id][class(byte)]
+// for 64 streams per wavefront.  The table lives in HBM per automaton and device and persists across launches.
+// A zero entry means "not built yet": the wavefront then builds that transition cooperatively — the members of the
+// set (one per lane) gather their slice dwords, the targets are OR-ed into an LDS bitmask (dedup), the bitmask is
+// enumerated in ascending order (canonical form), the set is looked up / inserted in a global hash table, and the
+// transition is published.  Publication is monotonic (0 -> value), every state's member chunk is written and
+// released (agent scope) before its id appears anywhere, chunks are whole 128-byte lines that nobody can have read
+// before, and member reads bypass L1 — so a stale view can only cause duplicate work, never a wrong set.
+// Sets with more than DFA_MAXM members, or a full table, yield DFA_EXIT: that stream is handed to the wave kernel
+// (resume mode) like in the group / pack kernels.  Accept pulses: the transition value carries a flag when the
+// target set contains accept states; such streams read the member chunk in the next pass and emit the pulses.
+__device__ __forceinline__ uint32_t aload(const uint32_t* ptr) {  // agent-scope load: bypasses this CU's L1
+  return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct DfaWave {
+  uint32_t* bits;   // [nw32] LDS bitmask, all zero between uses
+  uint32_t* mlist;  // [64] LDS: sorted members of the set under construction
+};
+
+// Build dfa_trans[id][cc]; whole wave, wave-uniform arguments and result.
+__device__ uint32_t dfa_build(const RxParams& p, const DfaWave& w, uint32_t id, uint32_t cc, uint32_t lane) {
+  {  // another wave may have built it since this wave's (possibly stale) look-up: re-read past the L1
+    const uint32_t now = aload(p.dfa_trans + (size_t)id * p.n_classes + cc);
+    if (now != 0u) return now;
+  }
+  const uint32_t ncls = p.n_classes;
+  const uint32_t* chunk = p.dfa_pool + (size_t)id * 32u;
+  const uint32_t n = aload(chunk);
+  // 1. targets of every member on this byte class -> bitmask
+  for (uint32_t q0 = 0; q0 < n; q0 += 64u) {
+    const uint32_t q = q0 + lane;
+    const bool valid = q < n;
+    const uint32_t e = valid ? aload(chunk + DFA_HDR_WORDS + q) : 0u;
+    const uint32_t s = e & RXE_TGT_MASK;
+    const uint32_t x = (valid && !(e & RXE_ACCEPT)) ? p.symidx_c[s * ncls + cc] : 0u;
+    if (x & RXE_SELF) atomicOr(&w.bits[s >> 5], 1u << (s & 31u));
+    if (x & RXE_INLINE) { const uint32_t t = x & RXE_TGT_MASK; atomicOr(&w.bits[t >> 5], 1u << (t & 31u)); }
+    uint64_t mo = wballot(x & RXE_OVF);
+    while (mo) {
+      const uint32_t src = (uint32_t)__builtin_ctzll(mo);
+      mo &= mo - 1;
+      const uint32_t off = bcast(x & RXE_TGT_MASK, src);
+      const uint32_t cnt = p.ovf[off];
+      for (uint32_t j0 = 0; j0 < cnt; j0 += 64u)
+        if (j0 + lane < cnt) { const uint32_t t = p.ovf[off + 1u + j0 + lane] & RXE_TGT_MASK; atomicOr(&w.bits[t >> 5], 1u << (t & 31u)); }
+    }
+  }
+  wave_sync();
+  // 2. enumerate the bitmask in ascending order (canonical member list), wiping it on the way
+  uint32_t cnt = 0, sumdeg = 0, hasacc = 0;
+  for (uint32_t w0 = 0; w0 < p.nw32; w0 += 64u) {
+    const uint32_t wi = w0 + lane;
+    uint32_t word = 0;
+    if (wi < p.nw32) { word = w.bits[wi]; w.bits[wi] = 0u; }
+    uint32_t pc = (uint32_t)__popc(word), incl = pc;
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) {  // inclusive prefix sum over the lanes
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+      if (lane >= d) incl += up;
+    }
+    uint32_t at = cnt + incl - pc;
+    const uint32_t accw = word ? p.accept_bits[wi] : 0u;
+    while (word) {
+      const uint32_t b = (uint32_t)__builtin_ctz(word);
+      word &= word - 1u;
+      const uint32_t st = wi * 32u + b;
+      const bool isacc = (accw >> b) & 1u;
+      if (at < 64u) w.mlist[at] = st | (isacc ? RXE_ACCEPT : 0u);
+      at++;
+      sumdeg += p.words[st + 1] - p.words[st];
+      hasacc |= isacc ? 1u : 0u;
+    }
+    cnt += bcast(incl, 63);
+  }
+  wave_sync();
+#pragma unroll
+  for (uint32_t d = 32; d >= 1; d >>= 1) {  // wave totals
+    sumdeg += (uint32_t)__shfl_xor((int)sumdeg, d);
+    hasacc |= (uint32_t)__shfl_xor((int)hasacc, d);
+  }
+  uint32_t nv;
+  if (cnt > DFA_MAXM) {
+    nv = DFA_EXIT;
+  } else {
+    // 3. hash of the member list
+    uint32_t hsh = lane < cnt ? (w.mlist[lane] & RXE_TGT_MASK) * 0x9E3779B1u + lane * 0x85EBCA6Bu : 0u;
+    hsh ^= hsh >> 15;
+#pragma unroll
+    for (uint32_t d = 32; d >= 1; d >>= 1) hsh += (uint32_t)__shfl_xor((int)hsh, d);
+    hsh = (hsh ^ (hsh >> 13)) * 0xC2B2AE35u + cnt;
+    // 4. find or insert
+    const uint32_t nch = cnt + DFA_HDR_WORDS <= 32u ? 1u : 2u;
+    uint32_t mine = 0;  // chunk index allocated by this wave (0 = none yet)
+    uint32_t found = 0;
+    uint32_t slot = hsh & p.dfa_hash_mask;
+    for (uint32_t probe = 0; probe <= p.dfa_hash_mask; probe++, slot = (slot + 1u) & p.dfa_hash_mask) {
+      uint32_t cand = aload(p.dfa_hash + slot);
+      if (cand == 0) {
+        if (!mine) {  // allocate + write + release, then publish
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(p.dfa_hdr + 1, nch);
+          base = bcast(base, 0);
+          if (base + nch > p.dfa_pool_chunks) { found = 0; mine = 0; break; }  // pool exhausted -> EXIT
+          uint32_t* nc = p.dfa_pool + (size_t)base * 32u;
+          if (lane == 0) { nc[0] = cnt; nc[1] = sumdeg; nc[2] = hasacc; }
+          if (lane < cnt) nc[DFA_HDR_WORDS + lane] = w.mlist[lane];
+          __threadfence();
+          mine = base;
+          if (lane == 0) atomicAdd(p.dfa_hdr + 2, 1u);
+        }
+        uint32_t old = 0;
+        if (lane == 0) old = atomicCAS(p.dfa_hash + slot, 0u, mine);
+        old = bcast(old, 0);
+        if (old == 0) { found = mine; break; }
+        cand = old;  // somebody else took the slot meanwhile: is it the same set?
+      }
+      const uint32_t* cc2 = p.dfa_pool + (size_t)cand * 32u;
+      bool diff = aload(cc2) != cnt;
+      if (!diff && lane < cnt) diff = (aload(cc2 + DFA_HDR_WORDS + lane) ^ w.mlist[lane]) != 0;
+      if (wballot(diff) == 0) { found = cand; break; }
+    }
+    nv = found ? (found | (hasacc ? DFA_ACC : 0u)) : DFA_EXIT;
+  }
+  // 5. publish the transition (monotonic 0 -> value)
+  if (lane == 0) {
+    __hip_atomic_store(p.dfa_trans + (size_t)id * ncls + cc, nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    atomicAdd(p.dfa_hdr + 3, 1u);
+  }
+  return nv;
+}
+
+template <bool STATS>
+__global__ void __launch_bounds__(256) rx_dfa_kernel(const RxParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wib = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  uint32_t* cmapw = lds;
+  const uint8_t* cmap = reinterpret_cast<const uint8_t*>(cmapw);
+  DfaWave w;
+  w.bits = lds + 64u + (size_t)wib * (p.nw32 + 64u);
+  w.mlist = w.bits + p.nw32;
+  for (uint32_t i = threadIdx.x; i < 64u; i += blockDim.x) cmapw[i] = p.byte_class[i];
+  for (uint32_t i = lane; i < p.nw32; i += 64u) w.bits[i] = 0u;
+  __syncthreads();
+  const uint32_t ncls = p.n_classes;
+  unsigned long long st_active = 0, st_edges = 0;
+
+  const uint32_t stream = (blockIdx.x * wpb + wib) * 64u + lane;
+  bool alive = stream < p.n_streams;
+  const uint8_t* base = p.bytes + (size_t)(alive ? stream : 0) * p.stride;
+  const bool aligned = (reinterpret_cast<uintptr_t>(base) & 3u) == 0;
+  auto load16 = [&](uint32_t chunk, uint32_t (&o)[4]) {  // 16 bytes of this lane's own stream
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint32_t off = chunk * 16u + 4u * q;
+      uint32_t v = 0;
+      if (alive) {
+        if (aligned && off + 4u <= p.stream_len) v = *reinterpret_cast<const uint32_t*>(base + off);
+        else
+          for (uint32_t b = 0; b < 4; b++)
+            if (off + b < p.stream_len) v |= (uint32_t)base[off + b] << (8u * b);
+      }
+      o[q] = v;
+    }
+  };
+  uint32_t cur = 1u | ((p.state0_entry & RXE_ACCEPT) ? DFA_ACC : 0u);  // id 1 = {state 0} (FPGA.v:134-147)
+  uint32_t win[4] = {0, 0, 0, 0}, nxt[4];
+  load16(0, nxt);
+  uint32_t am_word = 0;
+
+  for (uint32_t k = 0; k < p.n_passes; k++) {
+    const bool consume = k < p.n_consume;
+    const uint32_t id = cur & ~DFA_ACC;
+    // accept pulses of the current sets (rare): the wave reads one flagged stream's members at a time
+    {
+      uint64_t ma = wballot(alive && (cur & DFA_ACC));
+      while (ma) {
+        const uint32_t src = (uint32_t)__builtin_ctzll(ma);
+        ma &= ma - 1;
+        const uint32_t sid = bcast(id, src), sstream = bcast(stream, src);
+        const uint32_t* chunk = p.dfa_pool + (size_t)sid * 32u;
+        const uint32_t n = aload(chunk);
+        for (uint32_t q0 = 0; q0 < n; q0 += 64u) {
+          const uint32_t e = q0 + lane < n ? aload(chunk + DFA_HDR_WORDS + q0 + lane) : 0u;
+          uint32_t dummy = 0;
+          emit_events(p, (e & RXE_ACCEPT) != 0, e & RXE_TGT_MASK, sstream, k, lane, dummy);
+        }
+        if (lane == src) am_word |= 1u << (k & 31u);
+      }
+    }
+    if (consume) {
+      if ((k & 15u) == 0) {  // next 16 bytes of the own stream, as byte classes
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint32_t v = nxt[q];
+          win[q] = (uint32_t)cmap[v & 0xFFu] | ((uint32_t)cmap[(v >> 8) & 0xFFu] << 8) |
+                   ((uint32_t)cmap[(v >> 16) & 0xFFu] << 16) | ((uint32_t)cmap[v >> 24] << 24);
+        }
+        load16((k >> 4) + 1u, nxt);
+      }
+      const uint32_t kq = (k >> 2) & 3u;
+      const uint32_t wsel = kq == 0 ? win[0] : (kq == 1 ? win[1] : (kq == 2 ? win[2] : win[3]));
+      const uint32_t c = (wsel >> ((k & 3u) * 8u)) & 0xFFu;
+      if (STATS && alive) {
+        const uint32_t* chunk = p.dfa_pool + (size_t)id * 32u;
+        st_active += aload(chunk);
+        st_edges += aload(chunk + 1);
+      }
+      uint32_t v = 1u;
+      if (alive) {  // THE pass: one look-up per stream
+        v = p.dfa_trans[(size_t)id * ncls + c];
+      }
+      uint64_t mm = wballot(alive && v == 0u);
+      while (mm) {  // transitions not built yet: the whole wave builds one at a time
+        const uint32_t src = (uint32_t)__builtin_ctzll(mm);
+        const uint32_t bid = bcast(id, src), bc = bcast(c, src);
+        const uint32_t nv = dfa_build(p, w, bid, bc, lane);
+        const bool same = alive && v == 0u && id == bid && c == bc;
+        if (same) v = nv;
+        mm &= ~wballot(same);
+      }
+      // sets the table cannot hold: hand the stream (S_k as a bitmask row, k) to the wave kernel
+      uint64_t mx = wballot(alive && v == DFA_EXIT);
+      while (mx) {
+        const uint32_t src = (uint32_t)__builtin_ctzll(mx);
+        mx &= mx - 1;
+        const uint32_t sid = bcast(id, src), sstream = bcast(stream, src), sam = bcast(am_word, src);
+        uint32_t slot = 0;
+        if (lane == 0) slot = (uint32_t)atomicAdd(p.spill_count, 1ull);
+        slot = bcast(slot, 0);
+        const uint32_t* chunk = p.dfa_pool + (size_t)sid * 32u;
+        const uint32_t n = aload(chunk);
+        if (lane < n) { const uint32_t s = aload(chunk + DFA_HDR_WORDS + lane) & RXE_TGT_MASK; atomicOr(&w.bits[s >> 5], 1u << (s & 31u)); }
+        wave_sync();
+        uint32_t* row = p.spill_rows + (size_t)slot * p.nw64x2;
+        for (uint32_t i = lane; i < p.nw64x2; i += 64u) row[i] = i < p.nw32 ? w.bits[i] : 0u;
+        wave_sync();
+        for (uint32_t i = lane; i < p.nw32; i += 64u) w.bits[i] = 0u;
+        wave_sync();
+        if (lane == 0) {
+          p.spill_streams[slot] = sstream;
+          p.spill_k[slot] = k;
+          if (p.anymatch) p.anymatch[(size_t)sstream * p.anymatch_stride + (k >> 5)] = sam;
+        }
+        if (lane == src) alive = false;
+      }
+      if (alive) cur = v;
+    }
+    if (p.anymatch && ((k & 31u) == 31u || k + 1 == p.n_passes)) {
+      if (alive) p.anymatch[(size_t)stream * p.anymatch_stride + (k >> 5)] = am_word;
+      am_word = 0;
+    }
+  }
+  // final active sets: rows were zeroed by the host-side memset
+  if (p.final_active) {
+    uint64_t mf = wballot(alive);
+    while (mf) {
+      const uint32_t src = (uint32_t)__builtin_ctzll(mf);
+      mf &= mf - 1;
+      const uint32_t sid = bcast(cur & ~DFA_ACC, src), sstream = bcast(stream, src);
+      const uint32_t* chunk = p.dfa_pool + (size_t)sid * 32u;
+      const uint32_t n = aload(chunk);
+      if (lane < n) {
+        const uint32_t s = aload(chunk + DFA_HDR_WORDS + lane) & RXE_TGT_MASK;
+        atomicOr(&p.final_active[(size_t)sstream * p.nw64x2 + (s >> 5)], 1u << (s & 31u));
+      }
+    }
+  }
+  if (STATS) {
+    if (st_active) atomicAdd(&p.counters[1], st_active);
+    if (st_edges) atomicAdd(&p.counters[2], st_edges);
+  }
+}
+
 }  // namespace
 
 // -------------------------------------------------------------------------------------------------
@@ -1020,7 +1300,7 @@ int rx_pick_launch(uint32_t kernel, uint32_t size, uint32_t n_streams, int cu_co
   cfg->cu_count = cu_count;
   if (kernel == RX_KERNEL_AUTO) kernel = RX_KERNEL_SYM_PACK;  // fastest parity-checked kernel
   if (kernel != RX_KERNEL_CSR_WAVE && kernel != RX_KERNEL_SYM_WAVE && kernel != RX_KERNEL_SYM_GROUP &&
-      kernel != RX_KERNEL_SYM_PACK)
+      kernel != RX_KERNEL_SYM_PACK && kernel != RX_KERNEL_DFA)
     return RX_EINVAL;
   const uint32_t nw32 = (size + 31u) / 32u;
   p->nw32 = nw32;
@@ -1094,10 +1374,17 @@ int rx_launch(const RxParams& p, const RxLaunchCfg& cfg, void* hip_stream) {
     case RX_KERNEL_SYM_WAVE:
       return cfg.stats ? launch_one(rx_sym_wave_kernel<true>, p, cfg.grid_blocks, cfg.block_threads, cfg.lds_bytes, s)
                        : launch_one(rx_sym_wave_kernel<false>, p, cfg.grid_blocks, cfg.block_threads, cfg.lds_bytes, s);
+    case RX_KERNEL_DFA:
     case RX_KERNEL_SYM_PACK:
     case RX_KERNEL_SYM_GROUP: {
       int e;
-      if (cfg.kernel == RX_KERNEL_SYM_PACK) {
+      if (cfg.kernel == RX_KERNEL_DFA) {
+        const uint32_t wpb = 4;
+        const uint32_t grid = (p.n_streams + wpb * 64u - 1) / (wpb * 64u);
+        const uint32_t lds = (64u + wpb * (p.nw32 + 64u)) * 4u;
+        e = cfg.stats ? launch_one(rx_dfa_kernel<true>, p, grid ? grid : 1, wpb * 64u, lds, s)
+                      : launch_one(rx_dfa_kernel<false>, p, grid ? grid : 1, wpb * 64u, lds, s);
+      } else if (cfg.kernel == RX_KERNEL_SYM_PACK) {
         if (cfg.group_lanes == 2) e = launch_pack<2>(p, cfg, s);
         else if (cfg.group_lanes == 4) e = launch_pack<4>(p, cfg, s);
         else if (cfg.group_lanes == 8) e = launch_pack<8>(p, cfg, s);

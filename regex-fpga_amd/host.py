@@ -13,8 +13,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 MODE_FULL, MODE_TB_COMPAT = 0, 1
-KERNEL_AUTO, KERNEL_CSR_WAVE, KERNEL_SYM_WAVE, KERNEL_SYM_GROUP, KERNEL_SYM_PACK = 0, 1, 2, 3, 4
-KERNEL_NAMES = {0: "auto", 1: "csr_wave", 2: "sym_wave", 3: "sym_group", 4: "sym_pack"}
+KERNEL_AUTO, KERNEL_CSR_WAVE, KERNEL_SYM_WAVE, KERNEL_SYM_GROUP, KERNEL_SYM_PACK, KERNEL_DFA = 0, 1, 2, 3, 4, 5
+KERNEL_NAMES = {0: "auto", 1: "csr_wave", 2: "sym_wave", 3: "sym_group", 4: "sym_pack", 5: "dfa"}
 
 EVENT_DT = np.dtype([("stream", "<u4"), ("k", "<u4"), ("state", "<u4")])
 
@@ -56,7 +56,7 @@ class _Info(C.Structure):
 # every symbol include/rxmatch.h declares
 RE_ICASE, RE_DOTALL = 1, 2
 
-ABI_SYMBOLS = ["rx_compile_patterns", "rx_nfa_accept_pattern", "rx_nfa_save_coe", "rx_strerror", "rx_last_hip_error", "rx_abi_version", "rx_nfa_load_coe", "rx_nfa_from_words",
+ABI_SYMBOLS = ["rx_nfa_dfa_info", "rx_nfa_dfa_reset", "rx_compile_patterns", "rx_nfa_accept_pattern", "rx_nfa_save_coe", "rx_strerror", "rx_last_hip_error", "rx_abi_version", "rx_nfa_load_coe", "rx_nfa_from_words",
                "rx_nfa_get_info", "rx_nfa_words", "rx_nfa_free", "rx_trace_load_mem", "rx_free", "rx_match",
                "rx_match_sharded", "rx_plan_create", "rx_plan_upload", "rx_plan_set_device_input",
                "rx_plan_set_init_active", "rx_plan_launch", "rx_plan_sync", "rx_plan_kernel_times", "rx_plan_download", "rx_plan_free",
@@ -111,6 +111,8 @@ def lib():
     L.rx_compile_patterns.argtypes = [C.POINTER(C.c_char_p), sz, u32, C.POINTER(vp), C.c_char_p, sz]
     L.rx_nfa_accept_pattern.argtypes = [vp, u32, C.POINTER(C.c_int32)]
     L.rx_nfa_save_coe.argtypes = [vp, C.c_char_p]
+    L.rx_nfa_dfa_info.argtypes = [vp, i32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.rx_nfa_dfa_reset.argtypes = [vp, i32]
     L.rx_nfa_get_info.argtypes = [vp, C.POINTER(_Info)]
     L.rx_nfa_words.restype = C.POINTER(C.c_uint32)
     L.rx_nfa_words.argtypes = [vp, C.POINTER(sz)]
@@ -204,6 +206,15 @@ class Nfa:
         out = C.c_int32(-1)
         _chk(lib().rx_nfa_accept_pattern(self._h, int(state), C.byref(out)), "rx_nfa_accept_pattern")
         return out.value
+
+    def dfa_info(self, device=0):
+        """(states, transitions) of the lazy-DFA cache built so far on `device`."""
+        a, b = C.c_uint64(), C.c_uint64()
+        _chk(lib().rx_nfa_dfa_info(self._h, device, C.byref(a), C.byref(b)), "rx_nfa_dfa_info")
+        return a.value, b.value
+
+    def dfa_reset(self, device=0):
+        _chk(lib().rx_nfa_dfa_reset(self._h, device), "rx_nfa_dfa_reset")
 
     def save_coe(self, path):
         _chk(lib().rx_nfa_save_coe(self._h, os.fsencode(path)), f"rx_nfa_save_coe({path})")

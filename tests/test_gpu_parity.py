@@ -23,7 +23,7 @@ def kernels(rx):
             dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=4), dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=8),
             dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=16), dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=8),
             dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=16), dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=24),
-            dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=32), dict(kernel=rx.KERNEL_AUTO)]
+            dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=32), dict(kernel=rx.KERNEL_DFA), dict(kernel=rx.KERNEL_AUTO)]
 
 
 @pytest.fixture(scope="module")
@@ -262,6 +262,31 @@ def test_pair_clock_model_on_random_automata(rx, orx):
         with pytest.raises(rx.RxError):
             rx.match(nfa, rows[:1], mode=rx.MODE_TB_COMPAT, collect_stats=2)  # odd number of streams
     assert checked >= 10
+
+
+def test_lazy_dfa_cache_is_persistent_and_resettable(rx, orx, automata, traces):
+    """RX_KERNEL_DFA: the subset-construction cache grows on the device, persists across launches of the same
+    automaton handle, gives identical results cold, warm and after a reset, also on streams it has never seen."""
+    W, size = automata["snort_16"]
+    nfa = rx.Nfa.from_words(W, size)
+    wl = rx.workloads
+    lo, hi = traces[("snort_16", "lo")], traces[("snort_16", "hi")]
+    a = wl.trace_windows(lo, hi, 900, 700)
+    b = wl.trace_windows(lo, hi, 900, 700, first=5000)
+    ref_a, ref_b = orx.match_batch(W, size, a), orx.match_batch(W, size, b)
+    assert nfa.dfa_info(0) == (0, 0)
+    cold = rx.match(nfa, a, kernel=rx.KERNEL_DFA, collect_stats=True)
+    s1, t1 = nfa.dfa_info(0)
+    assert s1 > 100 and t1 > s1
+    warm = rx.match(nfa, a, kernel=rx.KERNEL_DFA, collect_stats=True)
+    assert nfa.dfa_info(0) == (s1, t1)                     # nothing new to build
+    other = rx.match(nfa, b, kernel=rx.KERNEL_DFA, collect_stats=True)
+    assert nfa.dfa_info(0)[0] >= s1
+    nfa.dfa_reset(0)
+    assert nfa.dfa_info(0) == (1, 0)
+    again = rx.match(nfa, b, kernel=rx.KERNEL_DFA, collect_stats=True)
+    for got, ref in ((cold, ref_a), (warm, ref_a), (other, ref_b), (again, ref_b)):
+        check_equal(rx, orx, got, ref, "dfa")
 
 
 def test_events_capacity_overflow(rx, orx, automata, traces, gpu_nfas):
