@@ -749,7 +749,7 @@ template <int S>
 struct PackLayout {
   static constexpr uint32_t FW = RX_GROUP_FILTER_WORDS;
   static constexpr uint32_t CAPW = RX_PACK_CAP;
-  static constexpr uint32_t WINW = 4;                       // 16 input bytes per stream
+  static constexpr uint32_t WINW = 16;                      // 64 input bytes (as byte classes) per stream
   static constexpr uint32_t STRIDE = 2u * FW + WINW + 1u;   // + any-match word; odd => banks spread
   static constexpr uint32_t WAVE_WORDS = 2u * CAPW + S * STRIDE + S;  // lists, stream regions, spill slots
   static constexpr uint32_t CMAPW = 64;                     // byte -> class map (256 bytes), shared by the block
@@ -783,46 +783,60 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
   if (stream0 >= p.n_streams) return;
   const uint32_t n_mine = p.n_streams - stream0 < (uint32_t)S ? p.n_streams - stream0 : (uint32_t)S;
   const bool owner = lane < n_mine;  // lane == stream slot it owns
-  const uint8_t* base = p.bytes + (size_t)(stream0 + (owner ? lane : 0)) * p.stride;
-  const bool aligned = (reinterpret_cast<uintptr_t>(base) & 3u) == 0;
-  auto load16 = [&](uint32_t chunk, uint32_t (&w)[4]) {
+  // input windows: lane = 4*slot + part fetches bytes [64*chunk + 16*part, +16) of stream `slot`
+  static_assert(S <= 16 || S % 4 == 0, "window loader covers 16 streams per wave-load");
+  constexpr uint32_t NLOAD = (S + 15) / 16;  // wave-loads per refill
+  auto load_win = [&](uint32_t chunk, uint32_t (&o)[NLOAD][4]) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const uint32_t o = chunk * 16u + 4u * q;
-      uint32_t v = 0;
-      if (owner) {
-        if (aligned && o + 4u <= p.stream_len) v = *reinterpret_cast<const uint32_t*>(base + o);
-        else
-          for (uint32_t b = 0; b < 4; b++)
-            if (o + b < p.stream_len) v |= (uint32_t)base[o + b] << (8u * b);
+    for (uint32_t g = 0; g < NLOAD; g++) {
+      const uint32_t slot = g * 16u + (lane >> 2), part = lane & 3u;
+      const bool have = slot < n_mine;
+      const uint8_t* bp = p.bytes + (size_t)(stream0 + (have ? slot : 0)) * p.stride;
+      const uint32_t off = chunk * 64u + part * 16u;
+      uint32_t v[4] = {0, 0, 0, 0};
+      if (have) {
+        if ((reinterpret_cast<uintptr_t>(bp + off) & 15u) == 0 && off + 16u <= p.stream_len) {
+          const uint4 q = *reinterpret_cast<const uint4*>(bp + off);
+          v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+#pragma unroll
+          for (int w4 = 0; w4 < 4; w4++)
+            for (uint32_t b = 0; b < 4; b++)
+              if (off + 4u * w4 + b < p.stream_len) v[w4] |= (uint32_t)bp[off + 4u * w4 + b] << (8u * b);
+        }
       }
-      w[q] = v;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; w4++) o[g][w4] = v[w4];
     }
   };
 
   for (uint32_t w = lane; w < S * L::STRIDE; w += 64u) sreg0[w] = 0u;
   if (owner) wl[lane] = p.state0_entry | (lane << SID_SHIFT);  // FPGA.v:134-147: current = {state 0}, per stream
   uint32_t N = n_mine, Nn = 0, tog = 0;
-  uint32_t nxt[4];
-  load16(0, nxt);
+  uint32_t nxt[NLOAD][4];
+  load_win(0, nxt);
   wave_sync();
   bool spilled = false;
 
   for (uint32_t k = 0; k < p.n_passes && !spilled; k++) {
     const bool consume = k < p.n_consume;
-    const uint32_t kk = k & 15u;
-    if (consume && kk == 0) {  // owners refill their stream's 16-byte window, fetch the next one
+    const uint32_t kk = k & 63u;
+    if (consume && kk == 0) {  // window refill: bytes -> byte classes on the way into LDS, next window requested
       wave_sync();
-      if (owner) {  // bytes -> byte classes on the way into the window
-        uint32_t* win = sreg0 + lane * L::STRIDE + 2u * L::FW;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const uint32_t v = nxt[q];
-          win[q] = (uint32_t)cmap[v & 0xFFu] | ((uint32_t)cmap[(v >> 8) & 0xFFu] << 8) |
-                   ((uint32_t)cmap[(v >> 16) & 0xFFu] << 16) | ((uint32_t)cmap[v >> 24] << 24);
+      for (uint32_t g = 0; g < NLOAD; g++) {
+        const uint32_t slot = g * 16u + (lane >> 2), part = lane & 3u;
+        if (slot < n_mine) {
+          uint32_t* win = sreg0 + slot * L::STRIDE + 2u * L::FW + part * 4u;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const uint32_t v = nxt[g][q];
+            win[q] = (uint32_t)cmap[v & 0xFFu] | ((uint32_t)cmap[(v >> 8) & 0xFFu] << 8) |
+                     ((uint32_t)cmap[(v >> 16) & 0xFFu] << 16) | ((uint32_t)cmap[v >> 24] << 24);
+          }
         }
       }
-      load16((k >> 4) + 1u, nxt);
+      load_win((k >> 6) + 1u, nxt);
       wave_sync();
     }
     uint32_t* clist = wl + tog * L::CAPW;
