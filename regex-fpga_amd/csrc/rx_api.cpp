@@ -387,7 +387,7 @@ extern "C" int rx_plan_create(const rx_nfa* nfa, const rx_opts* opts, size_t max
   const size_t nw64x2 = 2 * (((size_t)size + 63) / 64);
   auto fail = [&](int code) { rx_plan_free(p); return code; };
 #define PLCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(hip_fail(e_, #call)); } while (0)
-  PLCHK(hipMalloc((void**)&p->d_counters, 8 * sizeof(unsigned long long)));
+  PLCHK(hipMalloc((void**)&p->d_counters, 16 * sizeof(unsigned long long)));
   PLCHK(hipMalloc((void**)&p->d_events, std::max<size_t>(events_cap, 1) * sizeof(rx_event)));
   PLCHK(hipMalloc((void**)&p->d_mct, (size_t)size * sizeof(unsigned long long)));
   if (p->want_mc) PLCHK(hipMalloc((void**)&p->d_mc, max_streams * size * sizeof(uint32_t)));
@@ -535,10 +535,10 @@ static int auto_probe(rx_plan* p) {
   if (rc) return rc;
   cfg.stats = true;
   if ((rc = ensure_spill_area(p, a))) return rc;
-  HIPCHK(hipMemsetAsync(p->d_counters, 0, 8 * sizeof(unsigned long long), p->stream));
+  HIPCHK(hipMemsetAsync(p->d_counters, 0, 16 * sizeof(unsigned long long), p->stream));
   hipError_t e = (hipError_t)rx_launch(a, cfg, p->stream);
   if (e != hipSuccess) return hip_fail(e, "probe launch");
-  unsigned long long cnt[8];
+  unsigned long long cnt[16];
   HIPCHK(hipMemcpyAsync(cnt, p->d_counters, sizeof(cnt), hipMemcpyDeviceToHost, p->stream));
   HIPCHK(hipStreamSynchronize(p->stream));
   const double units = (double)a.n_streams * std::max<uint32_t>(a.stream_len, 1);
@@ -623,7 +623,7 @@ extern "C" int rx_plan_launch(rx_plan* p) {
     a.dfa_hash_mask = t.dfa_hash_mask;
   }
 
-  HIPCHK(hipMemsetAsync(p->d_counters, 0, 8 * sizeof(unsigned long long), p->stream));
+  HIPCHK(hipMemsetAsync(p->d_counters, 0, 16 * sizeof(unsigned long long), p->stream));
   HIPCHK(hipMemsetAsync(p->d_mct, 0, (size_t)h.size * sizeof(unsigned long long), p->stream));
   if (p->want_mc) HIPCHK(hipMemsetAsync(p->d_mc, 0, p->n_streams * h.size * sizeof(uint32_t), p->stream));
   if (p->n_timed >= 4096) p->n_timed = 0;  // nobody is reading the times: recycle the pool
@@ -693,10 +693,19 @@ extern "C" int rx_plan_download(rx_plan* p, rx_result* res) {
   rc = rx_plan_sync(p, nullptr);
   if (rc) return rc;
   const RxHostNfa& h = p->nfa->h;
-  unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long cnt[16] = {0};
   HIPCHK(hipMemcpy(cnt, p->d_counters, sizeof(cnt), hipMemcpyDeviceToHost));
   rx_stats& st = res->stats;
   st = rx_stats{};
+  if (getenv("RX_PROFILE_PACK") && p->cfg.kernel == RX_KERNEL_SYM_PACK) {
+    static const char* names[7] = {"list read", "accept check + window byte + filter clear", "slice gather", "filter atomics",
+                                   "ballots + slots + list writes", "overflow lists", "end of pass"};
+    unsigned long long tot = 0;
+    for (int q = 0; q < 7; q++) tot += cnt[8 + q];
+    for (int q = 0; q < 7 && tot; q++)
+      fprintf(stderr, "[rxmatch] pack pass phase %d %-44s %5.1f %%  (%.0f cycles per wave-pass)\n", q, names[q],
+              100.0 * cnt[8 + q] / tot, (double)cnt[8 + q] / ((double)((p->n_streams + 15) / 16) * p->params.n_passes));
+  }
   st.n_passes = p->params.n_passes;
   st.n_events = cnt[0];
   st.kernel_ms = p->last_ms;

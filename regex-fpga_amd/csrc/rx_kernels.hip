@@ -755,8 +755,19 @@ struct PackLayout {
   static constexpr uint32_t CMAPW = 64;                     // byte -> class map (256 bytes), shared by the block
 };
 
-template <int S, bool STATS>
+// PROF: diagnostic build only (RX_PROFILE_PACK=1): s_memtime stamps around the phases of a pass; the sums go to
+// counters[8..15], which nothing else reads.  Its run time is not representative — read the SHARES.
+template <int S, bool STATS, bool PROF>
 __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
+  unsigned long long t_prev = 0, t_sum[7] = {0, 0, 0, 0, 0, 0, 0};
+  auto stamp = [&](int phase) {
+    if (PROF) {
+      unsigned long long t;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      if (phase >= 0) t_sum[phase] += t - t_prev;
+      t_prev = t;
+    }
+  };
   using L = PackLayout<S>;
   constexpr uint32_t HMASK = 32u * L::FW - 1u;
   constexpr uint32_t SID_SHIFT = 24, SID_MASK = 31u << SID_SHIFT;
@@ -821,6 +832,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
   for (uint32_t k = 0; k < p.n_passes && !spilled; k++) {
     const bool consume = k < p.n_consume;
     const uint32_t kk = k & 63u;
+    stamp(-1);
     if (consume && kk == 0) {  // window refill: bytes -> byte classes on the way into LDS, next window requested
       wave_sync();
 #pragma unroll
@@ -883,6 +895,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       const uint32_t li = b0 + lane;
       const bool valid = li < N;
       const uint32_t e = valid ? clist[li] : 0u;
+      if (PROF) { asm volatile("" ::"v"(e)); stamp(0); }  // phase 0: refill check + list read
       const uint32_t sid = (e >> SID_SHIFT) & 31u;
       const uint32_t s = e & RXE_TGT_MASK;
       const bool acc = valid && (e & RXE_ACCEPT);
@@ -918,7 +931,9 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
           }
         }
       }
+      if (PROF) { asm volatile("" ::"v"(c)); stamp(1); }  // phase 1: accept check, window byte, filter clear
       const uint32_t x = (valid && !acc) ? symidx[s * ncls + c] : 0u;  // current byte's slice of row s
+      if (PROF) { asm volatile("" ::"v"(x)); stamp(2); }  // phase 2: slice gather
       // two candidates per lane: the state itself (self-loop) and the inline target; atomics back to back
       const bool p0 = (x & RXE_SELF) != 0, p1 = (x & RXE_INLINE) != 0;
       const uint32_t t1 = (x & (RXE_TGT_MASK | RXE_ACCEPT)) | (sid << SID_SHIFT);
@@ -929,6 +944,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       uint32_t* const idle = clist + lane;
       const uint32_t o0 = atomicOr(p0 ? &sreg[fnext_off + (h0 >> 5)] : idle, p0 ? bt0 : 0u);
       const uint32_t o1 = atomicOr(p1 ? &sreg[fnext_off + (h1 >> 5)] : idle, p1 ? bt1 : 0u);
+      if (PROF) { asm volatile("" ::"v"(o0), "v"(o1)); stamp(3); }  // phase 3: the two filter atomics
       const bool f0 = p0 && !(o0 & bt0), f1 = p1 && !(o1 & bt1);
       const bool m0 = p0 && (o0 & bt0), m1 = p1 && (o1 & bt1);
       const uint64_t mf0 = wballot(f0), mf1 = wballot(f1);
@@ -943,6 +959,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
         resolve(m0, e);
         resolve(m1, t1);
       }
+      stamp(4);  // phase 4: ballots, slots, list writes, rare duplicate resolution
       // rows with several targets on this byte (rare on snort_16, every pass on l7): the wave expands one such
       // list at a time, 64 targets per step, list lengths gathered up front
       uint64_t mo = wballot(x & RXE_OVF);
@@ -964,6 +981,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       }
     }
 
+    stamp(5);  // phase 5: overflow lists + loop control
     if (consume) {
       if (Nn > L::CAPW) {
         // the wave-wide list cannot hold the next sets: hand ALL of this wave's streams (S_k, k) to the
@@ -1006,7 +1024,10 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       }
       wave_sync();
     }
+    stamp(6);  // phase 6: end of pass (swap, wave sync, bitmap store)
   }
+  if (PROF && lane == 0)
+    for (int q = 0; q < 7; q++) atomicAdd(&p.counters[8 + q], t_sum[q]);
   // final active sets: rows were zeroed by the host-side memset; set the listed bits
   if (p.final_active && !spilled) {
     const uint32_t* clist = wl + tog * L::CAPW;
@@ -1374,8 +1395,10 @@ static int launch_pack(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s)
   const uint32_t waves = (p.n_streams + S - 1) / S;
   const uint32_t grid = (waves + wpb - 1) / wpb;
   const uint32_t lds = (L::CMAPW + wpb * L::WAVE_WORDS) * 4u;
-  return cfg.stats ? launch_one(rx_sym_pack_kernel<S, true>, p, grid ? grid : 1, wpb * 64u, lds, s)
-                   : launch_one(rx_sym_pack_kernel<S, false>, p, grid ? grid : 1, wpb * 64u, lds, s);
+  if (S == 16 && getenv("RX_PROFILE_PACK"))  // stamped diagnostic build, see the kernel's PROF note
+    return launch_one(rx_sym_pack_kernel<16, false, true>, p, grid ? grid : 1, wpb * 64u, lds, s);
+  return cfg.stats ? launch_one(rx_sym_pack_kernel<S, true, false>, p, grid ? grid : 1, wpb * 64u, lds, s)
+                   : launch_one(rx_sym_pack_kernel<S, false, false>, p, grid ? grid : 1, wpb * 64u, lds, s);
 }
 
 // returns a hipError_t value (0 = hipSuccess)
