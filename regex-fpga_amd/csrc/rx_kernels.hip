@@ -932,7 +932,11 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
         }
       }
       if (PROF) { asm volatile("" ::"v"(c)); stamp(1); }  // phase 1: accept check, window byte, filter clear
-      const uint32_t x = (valid && !acc) ? symidx[s * ncls + c] : 0u;  // current byte's slice of row s
+      // current byte's slice of row s; 32-bit byte offset from a scalar base (table < 4 GiB) keeps the address
+      // arithmetic out of the 64-bit VALU path
+      uint32_t x = 0u;
+      if (valid && !acc)
+        x = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(symidx) + ((s * ncls + c) << 2));
       if (PROF) { asm volatile("" ::"v"(x)); stamp(2); }  // phase 2: slice gather
       // two candidates per lane: the state itself (self-loop) and the inline target; atomics back to back
       const bool p0 = (x & RXE_SELF) != 0, p1 = (x & RXE_INLINE) != 0;
