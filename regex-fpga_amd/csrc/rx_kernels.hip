@@ -823,7 +823,10 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
 
   for (uint32_t w = lane; w < S * L::STRIDE; w += 64u) sreg0[w] = 0u;
   if (owner) wl[lane] = p.state0_entry | (lane << SID_SHIFT);  // FPGA.v:134-147: current = {state 0}, per stream
-  uint32_t N = n_mine, Nn = 0, tog = 0;
+  uint32_t N = n_mine, Nn = 0;
+  uint32_t* clist = wl;              // the two wave-wide lists and the two filter halves swap roles every pass
+  uint32_t* nlist = wl + L::CAPW;
+  uint32_t fcur_off = 0, fnext_off = L::FW;
   uint32_t nxt[NLOAD][4];
   load_win(0, nxt);
   wave_sync();
@@ -851,9 +854,6 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       load_win((k >> 6) + 1u, nxt);
       wave_sync();
     }
-    uint32_t* clist = wl + tog * L::CAPW;
-    uint32_t* nlist = wl + (tog ^ 1u) * L::CAPW;
-    const uint32_t fcur_off = tog * L::FW, fnext_off = (tog ^ 1u) * L::FW;
     Nn = 0;
 
     // exact check for a candidate whose filter bit was already set; wave-uniform call
@@ -891,27 +891,31 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       }
     };
 
+    // Predicates are kept as integer tests taken right at the ballot (one v_and + v_cmp each): a bool assembled from
+    // several flags reaches __ballot through a VGPR (v_cndmask + v_cmp), and this loop is bound by instruction issue.
+    constexpr uint32_t E_NONE = 0x80000000u;  // list-entry value of a lane without an entry (bit 31 is otherwise unused)
     for (uint32_t b0 = 0; b0 < N; b0 += 64u) {
       const uint32_t li = b0 + lane;
-      const bool valid = li < N;
-      const uint32_t e = valid ? clist[li] : 0u;
+      uint32_t e = clist[li];  // lanes past N read harmless LDS words of this wave and are overwritten below
+      if (li >= N) e = E_NONE;
       if (PROF) { asm volatile("" ::"v"(e)); stamp(0); }  // phase 0: refill check + list read
       const uint32_t sid = (e >> SID_SHIFT) & 31u;
       const uint32_t s = e & RXE_TGT_MASK;
-      const bool acc = valid && (e & RXE_ACCEPT);
       uint32_t* sreg = sreg0 + sid * L::STRIDE;
       {  // accept pulses
-        const uint64_t ma = wballot(acc);
+        const uint64_t ma = wballot((e & (E_NONE | RXE_ACCEPT)) == RXE_ACCEPT);
         if (ma) {
+          const bool acc = (e & (E_NONE | RXE_ACCEPT)) == RXE_ACCEPT;
           uint32_t dummy = 0;
           emit_events(p, acc, s, stream0 + sid, k, lane, dummy);
           if (acc) atomicOr(&sreg[2u * L::FW + L::WINW], 1u << (k & 31u));
         }
       }
       if (!consume) continue;
+      const bool live = (e & (E_NONE | RXE_ACCEPT)) == 0u;  // a real entry that is not an accept state: it has a row
       const uint32_t c = reinterpret_cast<const uint8_t*>(sreg + 2u * L::FW)[kk];  // class of that stream's input_char
-      if (valid) sreg[fcur_off + ((s & HMASK) >> 5)] = 0u;  // zero the filter word this entry went through
-      if (STATS && valid) {
+      if ((e & E_NONE) == 0u) sreg[fcur_off + ((s & HMASK) >> 5)] = 0u;  // zero the filter word this entry went through
+      if (STATS && (e & E_NONE) == 0u) {
         const uint32_t deg = rp[s + 1] - rp[s];
         st_active += 1;
         st_edges += deg;
@@ -935,33 +939,31 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       // current byte's slice of row s; 32-bit byte offset from a scalar base (table < 4 GiB) keeps the address
       // arithmetic out of the 64-bit VALU path
       uint32_t x = 0u;
-      if (valid && !acc)
-        x = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(symidx) + ((s * ncls + c) << 2));
+      if (live) x = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(symidx) + ((s * ncls + c) << 2));
       if (PROF) { asm volatile("" ::"v"(x)); stamp(2); }  // phase 2: slice gather
-      // two candidates per lane: the state itself (self-loop) and the inline target; atomics back to back
-      const bool p0 = (x & RXE_SELF) != 0, p1 = (x & RXE_INLINE) != 0;
+      // two candidates per lane: the state itself (self-loop) and the inline target.  Both filter atomics are issued
+      // by every lane, back to back, with one wait: a lane without a candidate ORs 0 into its own list slot (a no-op
+      // on a private address) instead of sitting out in a branch.
       const uint32_t t1 = (x & (RXE_TGT_MASK | RXE_ACCEPT)) | (sid << SID_SHIFT);
       const uint32_t h0 = e & HMASK, h1 = x & HMASK;
-      const uint32_t bt0 = 1u << (h0 & 31u), bt1 = 1u << (h1 & 31u);
-      // both filter atomics are issued by every lane, back to back, with one wait: a lane without a candidate
-      // ORs 0 into its own list slot (a no-op on a private address) instead of sitting out in a branch
+      const uint32_t v0 = (x & RXE_SELF) ? 1u << (h0 & 31u) : 0u;    // bit to set, 0 = no candidate
+      const uint32_t v1 = (x & RXE_INLINE) ? 1u << (h1 & 31u) : 0u;
       uint32_t* const idle = clist + lane;
-      const uint32_t o0 = atomicOr(p0 ? &sreg[fnext_off + (h0 >> 5)] : idle, p0 ? bt0 : 0u);
-      const uint32_t o1 = atomicOr(p1 ? &sreg[fnext_off + (h1 >> 5)] : idle, p1 ? bt1 : 0u);
+      const uint32_t o0 = atomicOr(v0 ? &sreg[fnext_off + (h0 >> 5)] : idle, v0);
+      const uint32_t o1 = atomicOr(v1 ? &sreg[fnext_off + (h1 >> 5)] : idle, v1);
       if (PROF) { asm volatile("" ::"v"(o0), "v"(o1)); stamp(3); }  // phase 3: the two filter atomics
-      const bool f0 = p0 && !(o0 & bt0), f1 = p1 && !(o1 & bt1);
-      const bool m0 = p0 && (o0 & bt0), m1 = p1 && (o1 & bt1);
-      const uint64_t mf0 = wballot(f0), mf1 = wballot(f1);
+      // fresh: candidate whose bit was clear; maybe: candidate whose bit was already set
+      const uint64_t mf0 = wballot((v0 & ~o0) != 0u), mf1 = wballot((v1 & ~o1) != 0u);
       uint32_t slot = Nn + rank_below(mf0);
-      if (f0 && slot < L::CAPW) nlist[slot] = e;
+      if ((v0 & ~o0) != 0u && slot < L::CAPW) nlist[slot] = e;
       Nn += (uint32_t)__popcll(mf0);
       slot = Nn + rank_below(mf1);
-      if (f1 && slot < L::CAPW) nlist[slot] = t1;
+      if ((v1 & ~o1) != 0u && slot < L::CAPW) nlist[slot] = t1;
       Nn += (uint32_t)__popcll(mf1);
-      if (wballot(m0 || m1)) {  // rare
+      if (wballot(((v0 & o0) | (v1 & o1)) != 0u)) {  // rare
         wave_sync();
-        resolve(m0, e);
-        resolve(m1, t1);
+        resolve((v0 & o0) != 0u, e);
+        resolve((v1 & o1) != 0u, t1);
       }
       stamp(4);  // phase 4: ballots, slots, list writes, rare duplicate resolution
       // rows with several targets on this byte (rare on snort_16, every pass on l7): the wave expands one such
@@ -1014,7 +1016,10 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
         }
         spilled = true;
       } else {
-        tog ^= 1u;  // current <- next (FPGA.v:733-737)
+        {  // current <- next (FPGA.v:733-737)
+          uint32_t* t = clist; clist = nlist; nlist = t;
+          const uint32_t f = fcur_off; fcur_off = fnext_off; fnext_off = f;
+        }
         N = Nn;
         wave_sync();
       }
@@ -1034,7 +1039,6 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
     for (int q = 0; q < 7; q++) atomicAdd(&p.counters[8 + q], t_sum[q]);
   // final active sets: rows were zeroed by the host-side memset; set the listed bits
   if (p.final_active && !spilled) {
-    const uint32_t* clist = wl + tog * L::CAPW;
     for (uint32_t li = lane; li < N; li += 64u) {
       const uint32_t e = clist[li];
       const uint32_t sq = e & RXE_TGT_MASK;
