@@ -751,7 +751,8 @@ struct PackLayout {
   static constexpr uint32_t CAPW = RX_PACK_CAP;
   static constexpr uint32_t WINW = 16;                      // 64 input bytes (as byte classes) per stream
   static constexpr uint32_t STRIDE = 2u * FW + WINW + 1u;   // + any-match word; odd => banks spread
-  static constexpr uint32_t WAVE_WORDS = 2u * CAPW + S * STRIDE + S;  // lists, stream regions, spill slots
+  static constexpr uint32_t LISTW = CAPW + 128u;            // a sweep appends at most 128 entries past CAPW: no bounds check
+  static constexpr uint32_t WAVE_WORDS = 2u * LISTW + S * STRIDE + S;  // lists, stream regions, spill slots
   static constexpr uint32_t CMAPW = 64;                     // byte -> class map (256 bytes), shared by the block
 };
 
@@ -778,7 +779,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
   uint32_t* cmapw = lds;                              // [64] byte -> class
   const uint8_t* cmap = reinterpret_cast<const uint8_t*>(cmapw);
   uint32_t* wl = lds + L::CMAPW + (size_t)wib * L::WAVE_WORDS;  // [2][CAPW] wave-wide lists
-  uint32_t* sreg0 = wl + 2u * L::CAPW;               // [S][STRIDE]: filters[2][FW], window[WINW], am word
+  uint32_t* sreg0 = wl + 2u * L::LISTW;              // [S][STRIDE]: filters[2][FW], window[WINW], am word
   uint32_t* slotw = sreg0 + S * L::STRIDE;           // [S] spill slots
   const uint32_t* __restrict__ rp = p.words;
   const uint32_t* __restrict__ symidx = p.symidx_c;
@@ -825,7 +826,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
   if (owner) wl[lane] = p.state0_entry | (lane << SID_SHIFT);  // FPGA.v:134-147: current = {state 0}, per stream
   uint32_t N = n_mine, Nn = 0;
   uint32_t* clist = wl;              // the two wave-wide lists and the two filter halves swap roles every pass
-  uint32_t* nlist = wl + L::CAPW;
+  uint32_t* nlist = wl + L::LISTW;
   uint32_t fcur_off = 0, fnext_off = L::FW;
   uint32_t nxt[NLOAD][4];
   load_win(0, nxt);
@@ -894,10 +895,11 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
     // Predicates are kept as integer tests taken right at the ballot (one v_and + v_cmp each): a bool assembled from
     // several flags reaches __ballot through a VGPR (v_cndmask + v_cmp), and this loop is bound by instruction issue.
     constexpr uint32_t E_NONE = 0x80000000u;  // list-entry value of a lane without an entry (bit 31 is otherwise unused)
-    for (uint32_t b0 = 0; b0 < N; b0 += 64u) {
+    const uint32_t Ns = (uint32_t)__builtin_amdgcn_readfirstlane((int)N);  // wave-uniform: keep the loop scalar
+    for (uint32_t b0 = 0; b0 < Ns; b0 += 64u) {
       const uint32_t li = b0 + lane;
       uint32_t e = clist[li];  // lanes past N read harmless LDS words of this wave and are overwritten below
-      if (li >= N) e = E_NONE;
+      if (li >= Ns) e = E_NONE;
       if (PROF) { asm volatile("" ::"v"(e)); stamp(0); }  // phase 0: refill check + list read
       const uint32_t sid = (e >> SID_SHIFT) & 31u;
       const uint32_t s = e & RXE_TGT_MASK;
@@ -914,7 +916,9 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       if (!consume) continue;
       const bool live = (e & (E_NONE | RXE_ACCEPT)) == 0u;  // a real entry that is not an accept state: it has a row
       const uint32_t c = reinterpret_cast<const uint8_t*>(sreg + 2u * L::FW)[kk];  // class of that stream's input_char
-      if ((e & E_NONE) == 0u) sreg[fcur_off + ((s & HMASK) >> 5)] = 0u;  // zero the filter word this entry went through
+      // zero the filter word this entry went through (lanes without an entry hit word 0 of slot 0's CURRENT filter,
+      // which is being wiped this pass anyway and is not read before the next swap)
+      sreg[fcur_off + ((s & HMASK) >> 5)] = 0u;
       if (STATS && (e & E_NONE) == 0u) {
         const uint32_t deg = rp[s + 1] - rp[s];
         st_active += 1;
@@ -954,12 +958,11 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       if (PROF) { asm volatile("" ::"v"(o0), "v"(o1)); stamp(3); }  // phase 3: the two filter atomics
       // fresh: candidate whose bit was clear; maybe: candidate whose bit was already set
       const uint64_t mf0 = wballot((v0 & ~o0) != 0u), mf1 = wballot((v1 & ~o1) != 0u);
-      uint32_t slot = Nn + rank_below(mf0);
-      if ((v0 & ~o0) != 0u && slot < L::CAPW) nlist[slot] = e;
-      Nn += (uint32_t)__popcll(mf0);
-      slot = Nn + rank_below(mf1);
-      if ((v1 & ~o1) != 0u && slot < L::CAPW) nlist[slot] = t1;
-      Nn += (uint32_t)__popcll(mf1);
+      if (Nn <= L::CAPW) {  // (wave-uniform) past that the pass ends in a hand-off anyway; keeps writes inside LISTW
+        if ((v0 & ~o0) != 0u) nlist[Nn + rank_below(mf0)] = e;
+        if ((v1 & ~o1) != 0u) nlist[Nn + (uint32_t)__popcll(mf0) + rank_below(mf1)] = t1;
+      }
+      Nn += (uint32_t)__popcll(mf0) + (uint32_t)__popcll(mf1);
       if (wballot(((v0 & o0) | (v1 & o1)) != 0u)) {  // rare
         wave_sync();
         resolve((v0 & o0) != 0u, e);
