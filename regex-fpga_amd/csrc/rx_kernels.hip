@@ -955,6 +955,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       uint32_t* const idle = clist + lane;
       const uint32_t o0 = atomicOr(v0 ? &sreg[fnext_off + (h0 >> 5)] : idle, v0);
       const uint32_t o1 = atomicOr(v1 ? &sreg[fnext_off + (h1 >> 5)] : idle, v1);
+      __builtin_amdgcn_sched_barrier(0);  // keep the first result's consumers behind the second atomic's issue
       if (PROF) { asm volatile("" ::"v"(o0), "v"(o1)); stamp(3); }  // phase 3: the two filter atomics
       // fresh: candidate whose bit was clear; maybe: candidate whose bit was already set
       const uint64_t mf0 = wballot((v0 & ~o0) != 0u), mf1 = wballot((v1 & ~o1) != 0u);
