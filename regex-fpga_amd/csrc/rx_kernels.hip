@@ -42,6 +42,10 @@ __device__ __forceinline__ uint64_t wballot(T pred) {
 __device__ __forceinline__ uint32_t rank_below(uint64_t m) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
+// base + number of set bits of m below this lane (the addend rides along in v_mbcnt_lo for free)
+__device__ __forceinline__ uint32_t rank_below_plus(uint64_t m, uint32_t base) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, base));
+}
 // The waves of a block are independent; ordering is only needed between the lanes of one wave,
 // which execute LDS instructions in program order.  This keeps the compiler from reordering.
 __device__ __forceinline__ void wave_sync() {
@@ -832,6 +836,11 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
   load_win(0, nxt);
   wave_sync();
   bool spilled = false;
+  // A lane without an entry still runs the unpredicated LDS operations of a pass (zero stores into the filter being
+  // wiped, OR 0 into the filter being filled): its pseudo entry points every lane at a different (slot, filter word)
+  // so that those no-ops do not pile up on one LDS address.
+  const uint32_t x_none = (lane / (uint32_t)S) << 5;
+  const uint32_t e_none = 0x80000000u | ((lane % (uint32_t)S) << SID_SHIFT) | x_none;
 
   for (uint32_t k = 0; k < p.n_passes && !spilled; k++) {
     const bool consume = k < p.n_consume;
@@ -894,12 +903,12 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
 
     // Predicates are kept as integer tests taken right at the ballot (one v_and + v_cmp each): a bool assembled from
     // several flags reaches __ballot through a VGPR (v_cndmask + v_cmp), and this loop is bound by instruction issue.
-    constexpr uint32_t E_NONE = 0x80000000u;  // list-entry value of a lane without an entry (bit 31 is otherwise unused)
+    constexpr uint32_t E_NONE = 0x80000000u;  // list-entry flag of a lane without an entry (bit 31 is otherwise unused)
     const uint32_t Ns = (uint32_t)__builtin_amdgcn_readfirstlane((int)N);  // wave-uniform: keep the loop scalar
     for (uint32_t b0 = 0; b0 < Ns; b0 += 64u) {
       const uint32_t li = b0 + lane;
       uint32_t e = clist[li];  // lanes past N read harmless LDS words of this wave and are overwritten below
-      if (li >= Ns) e = E_NONE;
+      if (li >= Ns) e = e_none;
       if (PROF) { asm volatile("" ::"v"(e)); stamp(0); }  // phase 0: refill check + list read
       const uint32_t sid = (e >> SID_SHIFT) & 31u;
       const uint32_t s = e & RXE_TGT_MASK;
@@ -916,8 +925,8 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       if (!consume) continue;
       const bool live = (e & (E_NONE | RXE_ACCEPT)) == 0u;  // a real entry that is not an accept state: it has a row
       const uint32_t c = reinterpret_cast<const uint8_t*>(sreg + 2u * L::FW)[kk];  // class of that stream's input_char
-      // zero the filter word this entry went through (lanes without an entry hit word 0 of slot 0's CURRENT filter,
-      // which is being wiped this pass anyway and is not read before the next swap)
+      // zero the filter word this entry went through (lanes without an entry hit some word of the CURRENT filter of
+      // a valid slot; that filter is being wiped this pass anyway and is not read before the next swap)
       sreg[fcur_off + ((s & HMASK) >> 5)] = 0u;
       if (STATS && (e & E_NONE) == 0u) {
         const uint32_t deg = rp[s + 1] - rp[s];
@@ -942,26 +951,27 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       if (PROF) { asm volatile("" ::"v"(c)); stamp(1); }  // phase 1: accept check, window byte, filter clear
       // current byte's slice of row s; 32-bit byte offset from a scalar base (table < 4 GiB) keeps the address
       // arithmetic out of the 64-bit VALU path
-      uint32_t x = 0u;
-      if (live) x = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(symidx) + ((s * ncls + c) << 2));
+      uint32_t x = x_none;
+      if (live)  // s < 2^24, ncls <= 256: the 24-bit multiply-add is a full-rate VALU op, v_mul_lo_u32 is quarter rate
+        x = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(symidx) + ((__umul24(s, ncls) + c) << 2));
       if (PROF) { asm volatile("" ::"v"(x)); stamp(2); }  // phase 2: slice gather
       // two candidates per lane: the state itself (self-loop) and the inline target.  Both filter atomics are issued
-      // by every lane, back to back, with one wait: a lane without a candidate ORs 0 into its own list slot (a no-op
-      // on a private address) instead of sitting out in a branch.
-      const uint32_t t1 = (x & (RXE_TGT_MASK | RXE_ACCEPT)) | (sid << SID_SHIFT);
+      // by every lane, back to back, with one wait: a lane without a candidate ORs 0 (a no-op) into the word its
+      // hash names anyway instead of sitting out in a branch or selecting another address.
+      constexpr uint32_t T1_MASK = RXE_TGT_MASK | RXE_ACCEPT;
+      const uint32_t t1 = (x & T1_MASK) | (e & ~T1_MASK);  // v_bfi: a live e has only its slot bits outside the mask
       const uint32_t h0 = e & HMASK, h1 = x & HMASK;
       const uint32_t v0 = (x & RXE_SELF) ? 1u << (h0 & 31u) : 0u;    // bit to set, 0 = no candidate
       const uint32_t v1 = (x & RXE_INLINE) ? 1u << (h1 & 31u) : 0u;
-      uint32_t* const idle = clist + lane;
-      const uint32_t o0 = atomicOr(v0 ? &sreg[fnext_off + (h0 >> 5)] : idle, v0);
-      const uint32_t o1 = atomicOr(v1 ? &sreg[fnext_off + (h1 >> 5)] : idle, v1);
+      const uint32_t o0 = atomicOr(&sreg[fnext_off + (h0 >> 5)], v0);
+      const uint32_t o1 = atomicOr(&sreg[fnext_off + (h1 >> 5)], v1);
       __builtin_amdgcn_sched_barrier(0);  // keep the first result's consumers behind the second atomic's issue
       if (PROF) { asm volatile("" ::"v"(o0), "v"(o1)); stamp(3); }  // phase 3: the two filter atomics
       // fresh: candidate whose bit was clear; maybe: candidate whose bit was already set
       const uint64_t mf0 = wballot((v0 & ~o0) != 0u), mf1 = wballot((v1 & ~o1) != 0u);
       if (Nn <= L::CAPW) {  // (wave-uniform) past that the pass ends in a hand-off anyway; keeps writes inside LISTW
-        if ((v0 & ~o0) != 0u) nlist[Nn + rank_below(mf0)] = e;
-        if ((v1 & ~o1) != 0u) nlist[Nn + (uint32_t)__popcll(mf0) + rank_below(mf1)] = t1;
+        if ((v0 & ~o0) != 0u) nlist[rank_below_plus(mf0, Nn)] = e;
+        if ((v1 & ~o1) != 0u) nlist[rank_below_plus(mf1, Nn + (uint32_t)__popcll(mf0))] = t1;
       }
       Nn += (uint32_t)__popcll(mf0) + (uint32_t)__popcll(mf1);
       if (wballot(((v0 & o0) | (v1 & o1)) != 0u)) {  // rare
