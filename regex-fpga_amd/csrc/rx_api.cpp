@@ -523,34 +523,40 @@ static int auto_probe(rx_plan* p) {
   p->auto_lanes = 16;
   p->probe_active = 0;
   if (p->n_streams * p->stream_len < (256u << 10)) return RX_OK;  // tiny batch: not worth a probe
-  RxParams a;
-  fill_common(p, a);
-  a.n_streams = (uint32_t)std::min<size_t>(p->n_streams, 512);
-  a.stream_len = (uint32_t)std::min<size_t>(p->stream_len, 1024);
-  a.n_passes = a.stream_len + 1;
-  a.n_consume = a.stream_len;
-  RxLaunchCfg cfg{};
-  cfg.group_lanes = 16;
-  int rc = rx_pick_launch(RX_KERNEL_SYM_PACK, a.size, a.n_streams, p->tab.cu_count, p->tab.lds_per_cu, &a, &cfg);
+  // one statistics run of the pack kernel with `lanes` streams per wavefront over the corner of the batch
+  auto run = [&](uint32_t lanes, double* active, double* spilled) -> int {
+    RxParams a;
+    fill_common(p, a);
+    a.n_streams = (uint32_t)std::min<size_t>(p->n_streams, 512);
+    a.stream_len = (uint32_t)std::min<size_t>(p->stream_len, 1024);
+    a.n_passes = a.stream_len + 1;
+    a.n_consume = a.stream_len;
+    RxLaunchCfg cfg{};
+    cfg.group_lanes = lanes;
+    int rc = rx_pick_launch(RX_KERNEL_SYM_PACK, a.size, a.n_streams, p->tab.cu_count, p->tab.lds_per_cu, &a, &cfg);
+    if (rc) return rc;
+    cfg.stats = true;
+    if ((rc = ensure_spill_area(p, a))) return rc;
+    HIPCHK(hipMemsetAsync(p->d_counters, 0, 16 * sizeof(unsigned long long), p->stream));
+    hipError_t e = (hipError_t)rx_launch(a, cfg, p->stream);
+    if (e != hipSuccess) return hip_fail(e, "probe launch");
+    unsigned long long cnt[16];
+    HIPCHK(hipMemcpyAsync(cnt, p->d_counters, sizeof(cnt), hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    const double units = (double)a.n_streams * std::max<uint32_t>(a.stream_len, 1);
+    *active = (double)cnt[1] / units;
+    *spilled = (double)cnt[3] / a.n_streams;
+    return RX_OK;
+  };
+  double active = 0, spilled = 0;
+  int rc = run(16, &active, &spilled);
   if (rc) return rc;
-  cfg.stats = true;
-  if ((rc = ensure_spill_area(p, a))) return rc;
-  HIPCHK(hipMemsetAsync(p->d_counters, 0, 16 * sizeof(unsigned long long), p->stream));
-  hipError_t e = (hipError_t)rx_launch(a, cfg, p->stream);
-  if (e != hipSuccess) return hip_fail(e, "probe launch");
-  unsigned long long cnt[16];
-  HIPCHK(hipMemcpyAsync(cnt, p->d_counters, sizeof(cnt), hipMemcpyDeviceToHost, p->stream));
-  HIPCHK(hipStreamSynchronize(p->stream));
-  const double units = (double)a.n_streams * std::max<uint32_t>(a.stream_len, 1);
-  p->probe_active = (double)cnt[1] / units;
-  const double spilled = (double)cnt[3] / a.n_streams;
-  if (p->probe_active > 6.0 || spilled > 0.02) {
-    p->auto_kernel = RX_KERNEL_SYM_WAVE;
-  } else {
+  p->probe_active = active;
+  if (active <= 6.0 && spilled <= 0.02) {
     // the pack kernel is fastest when one pass of a wavefront is ONE iteration with ~37 of the 64 lanes busy:
     // streams per wavefront ~ 37 / (active states per stream)   (snort_16: T 2.3 -> 16, U 1.15 -> 32)
     static const uint32_t choices[] = {8, 12, 16, 20, 24, 32};
-    const double want = 37.0 / std::max(p->probe_active, 0.5);
+    const double want = 37.0 / std::max(active, 0.5);
     uint32_t best = 16;
     double bd = 1e9;
     for (uint32_t c : choices) {
@@ -558,7 +564,13 @@ static int auto_probe(rx_plan* p) {
       if (d < bd) { bd = d; best = c; }
     }
     p->auto_lanes = best;
+    return RX_OK;
   }
+  // many active states per stream (rule sets): four streams per wavefront with the long list (512 entries) and
+  // the wider filters, if that form keeps (nearly) all of the sample; otherwise one wavefront per stream
+  if ((rc = run(4, &active, &spilled))) return rc;
+  if (spilled <= 0.02) p->auto_lanes = 4;
+  else p->auto_kernel = RX_KERNEL_SYM_WAVE;
   return RX_OK;
 }
 

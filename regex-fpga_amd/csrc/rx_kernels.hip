@@ -751,8 +751,9 @@ __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
 //   * next list would exceed RX_PACK_CAP => all S streams are handed to the wave kernel (resume).
 template <int S>
 struct PackLayout {
-  static constexpr uint32_t FW = RX_GROUP_FILTER_WORDS;
-  static constexpr uint32_t CAPW = RX_PACK_CAP;
+  // few streams per wavefront = automata/inputs with many active states per stream: longer list, wider filters
+  static constexpr uint32_t FW = S <= 4 ? 2u * RX_GROUP_FILTER_WORDS : RX_GROUP_FILTER_WORDS;
+  static constexpr uint32_t CAPW = S <= 4 ? 512u : RX_PACK_CAP;
   static constexpr uint32_t WINW = 16;                      // 64 input bytes (as byte classes) per stream
   static constexpr uint32_t STRIDE = 2u * FW + WINW + 1u;   // + any-match word; odd => banks spread
   static constexpr uint32_t LISTW = CAPW + 128u;            // a sweep appends at most 128 entries past CAPW: no bounds check
@@ -980,24 +981,40 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
         resolve((v1 & o1) != 0u, t1);
       }
       stamp(4);  // phase 4: ballots, slots, list writes, rare duplicate resolution
-      // rows with several targets on this byte (rare on snort_16, every pass on l7): the wave expands one such
-      // list at a time, 64 targets per step, list lengths gathered up front
+      // rows with several targets on this byte (rare on snort_16, every pass on l7 and on compiled rule sets):
+      // the target lists of as many such entries as fit are laid side by side over the 64 lanes (a scalar walk
+      // hands every entry its lane range), then ONE sweep loads and inserts them all
       uint64_t mo = wballot(x & RXE_OVF);
       if (__builtin_expect(mo != 0, 0)) {
         const uint32_t mycnt = (x & RXE_OVF) ? ovf[x & RXE_TGT_MASK] : 0u;
+        uint32_t total = 0, my_at = 0, my_sid = 0;
+        auto flush = [&]() {
+          const bool act = lane < total;
+          const uint32_t w = act ? ovf[my_at] : 0u;
+          insert(act, (w & (RXE_TGT_MASK | RXE_ACCEPT)) | (my_sid << SID_SHIFT), sreg0 + my_sid * L::STRIDE);
+          total = 0;
+        };
         do {
           const uint32_t src = (uint32_t)__builtin_ctzll(mo);
           mo &= mo - 1;
           const uint32_t off = bcast(x & RXE_TGT_MASK, src);
           const uint32_t osid = bcast(sid, src);
-          uint32_t* oreg = sreg0 + osid * L::STRIDE;
           const uint32_t cnt = bcast(mycnt, src);
-          for (uint32_t q0 = 0; q0 < cnt; q0 += 64u) {
-            const bool act = q0 + lane < cnt;
-            const uint32_t w = act ? ovf[off + 1u + q0 + lane] : 0u;
-            insert(act, (w & (RXE_TGT_MASK | RXE_ACCEPT)) | (osid << SID_SHIFT), oreg);
+          if (total != 0 && total + cnt > 64u) flush();
+          if (cnt > 64u) {  // a list longer than the wave: swept on its own
+            uint32_t* oreg = sreg0 + osid * L::STRIDE;
+            for (uint32_t q0 = 0; q0 < cnt; q0 += 64u) {
+              const bool act = q0 + lane < cnt;
+              const uint32_t w = act ? ovf[off + 1u + q0 + lane] : 0u;
+              insert(act, (w & (RXE_TGT_MASK | RXE_ACCEPT)) | (osid << SID_SHIFT), oreg);
+            }
+          } else {
+            const uint32_t d = lane - total;  // lanes [total, total+cnt) take this entry's targets
+            if (d < cnt) { my_at = off + 1u + d; my_sid = osid; }
+            total += cnt;
           }
         } while (mo);
+        if (total != 0) flush();
       }
     }
 

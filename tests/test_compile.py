@@ -159,20 +159,31 @@ def test_compiled_ruleset_on_gpu(rx, orx):
 
 
 @pytest.mark.gpu
-def test_auto_picks_wave_kernel_for_large_active_sets(rx, orx):
-    """RX_KERNEL_AUTO probes the batch: on the ruleset stand-in (about 14 active states per byte) it must choose
-    the wavefront-per-stream slice kernel, on snort_16 trace windows the pack kernel — with identical results."""
+def test_auto_probe_picks_the_kernel_by_active_set_size(rx, orx):
+    """RX_KERNEL_AUTO probes the batch: snort_16 trace windows (2-3 active states per stream) and the ruleset
+    stand-in (about 14, bursts of 70) both go to the pack kernel (16 resp. 4 streams per wavefront); an automaton
+    that keeps 300 states active goes to the wavefront-per-stream slice kernel — with identical results."""
     wl = rx.workloads
+    from nfa_util import blowup_nfa
+    W, size = blowup_nfa(300)
+    wide = rx.Nfa.from_words(W, size)
+    rng = np.random.default_rng(7)
+    wrows = rng.choice(np.array([0x41, 0x43, 0x43, 0x43], dtype=np.uint8), size=(512, 640))
+    wref = orx.match_batch(W, size, wrows)
+    wgot = rx.match(wide, wrows, collect_stats=True)
+    assert rx.host.KERNEL_NAMES[wgot["stats"]["kernel_used"]] == "sym_wave"
+    assert np.array_equal(wgot["final_active"], wref["final_active"]) and wgot["stats"]["alg_bytes"] == wref["stats"]["alg_bytes"]
     pats = wl.synthetic_ruleset()
     nfa = rx.Nfa.compile(pats)
     rows = wl.ruleset_traffic(pats, 640, 1024)
     ref = orx.match_batch(nfa.words, nfa.size, rows)
     got = rx.match(nfa, rows, collect_stats=True)
-    assert rx.host.KERNEL_NAMES[got["stats"]["kernel_used"]] == "sym_wave"
+    assert rx.host.KERNEL_NAMES[got["stats"]["kernel_used"]] == "sym_pack"
     assert got["n_events"] == ref["n_events"] and np.array_equal(got["events"], ref["events"].astype(got["events"].dtype))
     assert np.array_equal(got["final_active"], ref["final_active"]) and got["stats"]["alg_bytes"] == ref["stats"]["alg_bytes"]
     for kern in (dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=16), dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=8),
-                 dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=8)):
+                 dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=8), dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=2),
+                 dict(kernel=rx.KERNEL_SYM_WAVE)):
         g2 = rx.match(nfa, rows, collect_stats=True, **kern)
         assert np.array_equal(g2["events"], got["events"]) and np.array_equal(g2["final_active"], got["final_active"]), kern
         assert g2["stats"]["alg_bytes"] == ref["stats"]["alg_bytes"], kern
