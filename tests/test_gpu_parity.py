@@ -21,7 +21,8 @@ def kernels(rx):
     return [dict(kernel=rx.KERNEL_CSR_WAVE), dict(kernel=rx.KERNEL_SYM_WAVE),
             dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=1), dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=2),
             dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=4), dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=8),
-            dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=16), dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=8),
+            dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=16), dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=4),
+            dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=8),
             dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=16), dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=24),
             dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=32), dict(kernel=rx.KERNEL_DFA), dict(kernel=rx.KERNEL_AUTO)]
 
@@ -239,6 +240,29 @@ def test_random_automata(rx, orx, kernels):
         for kern in kernels:
             got = rx.match(nfa, rows, mode=mode, **kern, want_match_count=True, collect_stats=True)
             check_equal(rx, orx, got, ref, ("random", trial, kern))
+
+
+def test_more_than_65536_states(rx, orx, kernels):
+    """State ids above 16 bits: the pack kernel's list entries then keep the full 24-bit state field and take the
+    byte class from the stream window (its WIDE build); every kernel must agree with the oracle there too."""
+    size = 70000
+    hi = [65535, 65536, 66000, 69000, 69001, 69990]
+    e = [(0, c, 1) for c in range(256)] + [(1, c, 1) for c in range(256)]
+    for src in (0, 1):
+        e += [(src, ord("a"), 69000), (src, ord("x"), 66000), (src, ord("q"), 65535)]
+    e += [(69000, ord("a"), 69000), (69000, ord("b"), 69001)]                      # a+b -> accept 69001
+    e += [(66000, ord("y"), t) for t in (65536, 69990, 300)]                     # several targets on one byte
+    e += [(65536, ord("z"), 69999), (69990, ord("z"), 69999), (300, ord("z"), 2)]  # accepts 69999 and 2
+    e += [(65535, ord("q"), 65535), (65535, ord("b"), 69001)]
+    W = build_words(size, e)
+    nfa = rx.Nfa.from_words(W, size)
+    rng = np.random.default_rng(65536)
+    rows = rng.choice(np.frombuffer(b"aabxyzq.", np.uint8), size=(40, 300))
+    ref = orx.match_batch(W, size, rows, want_match_count=True)
+    assert ref["n_events"] > 50 and {int(s) for s in ref["events"]["state"]} >= {2, 69001, 69999}
+    for kern in kernels:
+        got = rx.match(nfa, rows, **kern, want_match_count=True, collect_stats=True)
+        check_equal(rx, orx, got, ref, ("wide", kern))
 
 
 def test_pair_clock_model_on_random_automata(rx, orx):
