@@ -28,6 +28,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "rx_internal.hpp"
 
@@ -843,28 +844,43 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
   const uint32_t x_none = (lane / (uint32_t)S) << 5;
   const uint32_t e_none = 0x80000000u | ((lane % (uint32_t)S) << SID_SHIFT) | x_none;
 
-  for (uint32_t k = 0; k < p.n_passes && !spilled; k++) {
-    const bool consume = k < p.n_consume;
-    const uint32_t kk = k & 63u;
-    stamp(-1);
-    if (consume && kk == 0) {  // window refill: bytes -> byte classes on the way into LDS, next window requested
-      wave_sync();
+  // window refill at a pass k that is a multiple of 64: bytes -> byte classes on the way into LDS, next window requested
+  auto refill = [&](uint32_t k) {
+    wave_sync();
 #pragma unroll
-      for (uint32_t g = 0; g < NLOAD; g++) {
-        const uint32_t slot = g * 16u + (lane >> 2), part = lane & 3u;
-        if (slot < n_mine) {
-          uint32_t* win = sreg0 + slot * L::STRIDE + 2u * L::FW + part * 4u;
+    for (uint32_t g = 0; g < NLOAD; g++) {
+      const uint32_t slot = g * 16u + (lane >> 2), part = lane & 3u;
+      if (slot < n_mine) {
+        uint32_t* win = sreg0 + slot * L::STRIDE + 2u * L::FW + part * 4u;
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const uint32_t v = nxt[g][q];
-            win[q] = (uint32_t)cmap[v & 0xFFu] | ((uint32_t)cmap[(v >> 8) & 0xFFu] << 8) |
-                     ((uint32_t)cmap[(v >> 16) & 0xFFu] << 16) | ((uint32_t)cmap[v >> 24] << 24);
-          }
+        for (int q = 0; q < 4; q++) {
+          const uint32_t v = nxt[g][q];
+          win[q] = (uint32_t)cmap[v & 0xFFu] | ((uint32_t)cmap[(v >> 8) & 0xFFu] << 8) |
+                   ((uint32_t)cmap[(v >> 16) & 0xFFu] << 16) | ((uint32_t)cmap[v >> 24] << 24);
         }
       }
-      load_win((k >> 6) + 1u, nxt);
-      wave_sync();
     }
+    load_win((k >> 6) + 1u, nxt);
+    wave_sync();
+  };
+  // per-pass any-match bits of 32 passes: one word per stream, stored by the stream's owner lane
+  auto store_anymatch = [&](uint32_t word) {
+    wave_sync();
+    if (owner) {
+      uint32_t* am = sreg0 + lane * L::STRIDE + 2u * L::FW + L::WINW;
+      p.anymatch[(size_t)(stream0 + lane) * p.anymatch_stride + word] = *am;
+      *am = 0u;
+    }
+    wave_sync();
+  };
+
+  // One pass (FPGA.v:158-741 for S streams).  `consume` is a compile-time tag: the passes that take an input byte are
+  // driven by the chunked loops below (no per-pass refill / bitmap / mode tests); FULL mode's pass N only looks for
+  // accept states.
+  auto pass = [&](const uint32_t k, auto consume_tag) {
+    constexpr bool consume = decltype(consume_tag)::value;
+    const uint32_t kk = k & 63u;
+    stamp(-1);
     Nn = 0;
 
     // exact check for a candidate whose filter bit was already set; wave-uniform call
@@ -1055,17 +1071,29 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
         wave_sync();
       }
     }
-    if (!spilled && p.anymatch && ((k & 31u) == 31u || k + 1 == p.n_passes)) {
-      wave_sync();
-      if (owner) {
-        uint32_t* am = sreg0 + lane * L::STRIDE + 2u * L::FW + L::WINW;
-        p.anymatch[(size_t)(stream0 + lane) * p.anymatch_stride + (k >> 5)] = *am;
-        *am = 0u;
-      }
-      wave_sync();
+    stamp(6);  // phase 6: end of pass (swap, wave sync)
+  };
+
+  uint32_t k = 0;
+  const uint32_t n_consume = p.n_consume < p.n_passes ? p.n_consume : p.n_passes;
+  while (k < n_consume && !spilled) {  // k is a multiple of 64 here
+    refill(k);
+    const uint32_t kend = n_consume - k < 64u ? n_consume : k + 64u;
+    while (k < kend && !spilled) {
+      const uint32_t k32 = kend - k < 32u ? kend : k + 32u;
+      do {
+        pass(k, std::true_type{});
+        k++;
+      } while (k < k32 && !spilled);
+      if (!spilled && p.anymatch && (k & 31u) == 0u) store_anymatch((k >> 5) - 1u);
     }
-    stamp(6);  // phase 6: end of pass (swap, wave sync, bitmap store)
   }
+  while (k < p.n_passes && !spilled) {  // RX_MODE_FULL: pass N
+    pass(k, std::false_type{});
+    k++;
+    if (p.anymatch && (k & 31u) == 0u) store_anymatch((k >> 5) - 1u);
+  }
+  if (!spilled && p.anymatch && (k & 31u) != 0u) store_anymatch(k >> 5);
   if (PROF && lane == 0)
     for (int q = 0; q < 7; q++) atomicAdd(&p.counters[8 + q], t_sum[q]);
   // final active sets: rows were zeroed by the host-side memset; set the listed bits
