@@ -70,3 +70,28 @@ def late_blowup_nfa(width):
     for i, s in enumerate(wide):
         e += [(s, ord("Y"), s), (s, ord("Y"), wide[(i + 1) % width]), (s, ord("B"), 3)]
     return build_words(size, e), size
+
+
+def convention_nfa(rng, size, alphabet=8, n_first=3, max_deg=4):
+    """Random automaton in the shipped tables' convention: state 0 -> `.*` state 1 on all 256
+    bytes, state 1 loops on all 256 bytes, both start patterns on `n_first` byte values (sometimes several targets
+    on one byte), nothing leads back to 0 or 1, accepts are empty rows.  Qualifies for always-on-state folding."""
+    assert size >= 4
+    e = [(0, c, 1) for c in range(256)] + [(1, c, 1) for c in range(256)]
+    sinks = set(rng.choice(np.arange(2, size), size=max(1, (size - 2) // 4), replace=False).tolist())
+    firsts = set()
+    for _ in range(n_first):
+        c = int(rng.integers(0, alphabet))
+        for _ in range(int(rng.integers(1, 4))):
+            firsts.add((c, int(rng.integers(2, size))))
+    for c, t in firsts:
+        e += [(0, c, t), (1, c, t)]
+    inner = set()
+    for s in range(2, size):
+        if s in sinks:
+            continue
+        for _ in range(int(rng.integers(1, max_deg + 1))):
+            inner.add((s, int(rng.integers(0, alphabet)), int(rng.integers(2, size))))
+    inner = list(inner)
+    rng.shuffle(inner)
+    return build_words(size, e + inner), size

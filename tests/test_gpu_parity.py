@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN
-from nfa_util import blowup_nfa, build_words, kat_ab, late_blowup_nfa, random_nfa
+from nfa_util import blowup_nfa, build_words, convention_nfa, kat_ab, late_blowup_nfa, random_nfa
 
 pytestmark = pytest.mark.gpu
 G = json.load(open(os.path.join(GOLDEN, "golden.json")))
@@ -240,6 +240,24 @@ def test_random_automata(rx, orx, kernels):
         for kern in kernels:
             got = rx.match(nfa, rows, mode=mode, **kern, want_match_count=True, collect_stats=True)
             check_equal(rx, orx, got, ref, ("random", trial, kern))
+
+
+def test_automata_in_the_reference_convention(rx, orx, kernels):
+    """Random automata built like the shipped tables (state 0 -> pinned `.*` state 1 on every byte, state 1 loops
+    on every byte, both start patterns, nothing leads back): the shape the pinned-state logic of the group kernel
+    and the list kernels see in practice."""
+    rng = np.random.default_rng(1711)
+    for trial in range(30):
+        alpha = int(rng.integers(2, 10))
+        Wc, sz = convention_nfa(rng, int(rng.integers(4, 200)), alphabet=alpha, n_first=int(rng.integers(1, 5)))
+        nfa = rx.Nfa.from_words(Wc, sz)
+        ns, sl = int(rng.integers(1, 70)), int(rng.integers(0, 260))
+        rows = rng.integers(0, alpha, size=(ns, sl), dtype=np.uint8)
+        mode = int(trial & 1)
+        ref = orx.match_batch(Wc, sz, rows, mode=mode, want_match_count=True)
+        for kern in kernels:
+            got = rx.match(nfa, rows, mode=mode, **kern, want_match_count=True, collect_stats=True)
+            check_equal(rx, orx, got, ref, ("convention", trial, kern))
 
 
 def test_more_than_65536_states(rx, orx, kernels):
