@@ -62,6 +62,7 @@ struct DevTables {
   uint32_t* ovf = nullptr;
   uint32_t* accept_bits = nullptr;
   uint32_t* symidx_c = nullptr;
+  uint32_t *symidx_p = nullptr, *ovf_dir = nullptr;  // look-ahead pruning tables (pack kernel), may stay null
   uint32_t* byte_class = nullptr;
   // lazy-DFA cache (allocated by the first RX_KERNEL_DFA launch)
   uint32_t *dfa_trans = nullptr, *dfa_pool = nullptr, *dfa_hash = nullptr, *dfa_hdr = nullptr;
@@ -152,6 +153,8 @@ extern "C" void rx_nfa_free(rx_nfa* nfa) {
     (void)hipFree(kv.second.ovf);
     (void)hipFree(kv.second.accept_bits);
     (void)hipFree(kv.second.symidx_c);
+    (void)hipFree(kv.second.symidx_p);
+    (void)hipFree(kv.second.ovf_dir);
     (void)hipFree(kv.second.byte_class);
     (void)hipFree(kv.second.dfa_trans);
     (void)hipFree(kv.second.dfa_pool);
@@ -219,6 +222,10 @@ static int get_dev_tables(const rx_nfa* cnfa, int device, DevTables* out) {
   if ((rc = upload_vec(nfa->h.ovf, &t.ovf))) return rc;
   if ((rc = upload_vec(nfa->h.accept_bits, &t.accept_bits))) return rc;
   if ((rc = upload_vec(nfa->h.symidx_c, &t.symidx_c))) return rc;
+  if (!nfa->h.ovf_dir.empty()) {
+    if ((rc = upload_vec(nfa->h.symidx_p, &t.symidx_p))) return rc;
+    if ((rc = upload_vec(nfa->h.ovf_dir, &t.ovf_dir))) return rc;
+  }
   {
     std::vector<uint32_t> bc(64);
     memcpy(bc.data(), nfa->h.byte_class, 256);
@@ -329,6 +336,7 @@ struct rx_plan {
   bool auto_decided = false;   // RX_KERNEL_AUTO: the probe has run for the current batch
   uint32_t auto_kernel = RX_KERNEL_SYM_PACK;
   uint32_t auto_lanes = 16;    // streams per wavefront chosen for the pack kernel
+  bool auto_prune = false;     // look-ahead pruning chosen by the probe
   double probe_active = 0;     // active states per stream-byte seen by the probe
   RxParams params{};
   RxLaunchCfg cfg{};
@@ -490,6 +498,8 @@ static void fill_common(rx_plan* p, RxParams& a) {
   a.ovf = p->tab.ovf;
   a.accept_bits = p->tab.accept_bits;
   a.symidx_c = p->tab.symidx_c;
+  a.symidx_p = p->tab.symidx_p;
+  a.ovf_dir = p->tab.ovf_dir;
   a.byte_class = p->tab.byte_class;
   a.n_classes = h.n_classes;
   a.size = h.size;
@@ -521,10 +531,13 @@ static int ensure_spill_area(rx_plan* p, RxParams& a) {
 static int auto_probe(rx_plan* p) {
   p->auto_kernel = RX_KERNEL_SYM_PACK;
   p->auto_lanes = 16;
+  p->auto_prune = false;
   p->probe_active = 0;
   if (p->n_streams * p->stream_len < (256u << 10)) return RX_OK;  // tiny batch: not worth a probe
-  // one statistics run of the pack kernel with `lanes` streams per wavefront over the corner of the batch
-  auto run = [&](uint32_t lanes, double* active, double* spilled) -> int {
+  // one run of the pack kernel with `lanes` streams per wavefront over the corner of the batch: the statistics
+  // build (counters) or, with stats = false, the build that would really run (only the hand-off count is read)
+  unsigned long long cnt[16];
+  auto run = [&](uint32_t lanes, bool stats, bool prune, double* spilled) -> int {
     RxParams a;
     fill_common(p, a);
     a.n_streams = (uint32_t)std::min<size_t>(p->n_streams, 512);
@@ -535,40 +548,56 @@ static int auto_probe(rx_plan* p) {
     cfg.group_lanes = lanes;
     int rc = rx_pick_launch(RX_KERNEL_SYM_PACK, a.size, a.n_streams, p->tab.cu_count, p->tab.lds_per_cu, &a, &cfg);
     if (rc) return rc;
-    cfg.stats = true;
+    cfg.stats = stats;
+    cfg.prune = prune;
     if ((rc = ensure_spill_area(p, a))) return rc;
     HIPCHK(hipMemsetAsync(p->d_counters, 0, 16 * sizeof(unsigned long long), p->stream));
     hipError_t e = (hipError_t)rx_launch(a, cfg, p->stream);
     if (e != hipSuccess) return hip_fail(e, "probe launch");
-    unsigned long long cnt[16];
     HIPCHK(hipMemcpyAsync(cnt, p->d_counters, sizeof(cnt), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
-    const double units = (double)a.n_streams * std::max<uint32_t>(a.stream_len, 1);
-    *active = (double)cnt[1] / units;
     *spilled = (double)cnt[3] / a.n_streams;
     return RX_OK;
   };
-  double active = 0, spilled = 0;
-  int rc = run(16, &active, &spilled);
+  const double units = (double)std::min<size_t>(p->n_streams, 512) * std::max<size_t>(std::min<size_t>(p->stream_len, 1024), 1);
+  double spilled = 0;
+  int rc = run(16, true, false, &spilled);
   if (rc) return rc;
+  const double active = (double)cnt[1] / units, spilled16 = spilled;
   p->probe_active = active;
-  if (active <= 6.0 && spilled <= 0.02) {
-    // the pack kernel is fastest when one pass of a wavefront is ONE iteration with ~37 of the 64 lanes busy:
-    // streams per wavefront ~ 37 / (active states per stream)   (snort_16: T 2.3 -> 16, U 1.15 -> 32)
+  // the pack kernel is fastest when one pass of a wavefront is ONE sweep with ~37 of the 64 lanes busy:
+  // streams per wavefront ~ 37 / (list entries per stream)   (snort_16: T 2.3 -> 16, U 1.15 -> 32)
+  auto lanes_for = [](double entries) {
     static const uint32_t choices[] = {8, 12, 16, 20, 24, 32};
-    const double want = 37.0 / std::max(active, 0.5);
+    const double want = 37.0 / std::max(entries, 0.5);
     uint32_t best = 16;
     double bd = 1e9;
     for (uint32_t c : choices) {
       const double d = std::abs((double)c - want);
       if (d < bd) { bd = d; best = c; }
     }
-    p->auto_lanes = best;
+    return best;
+  };
+  // multi-target rows met by at least 2 % of the list entries: look-ahead pruning pays (rule sets, l7-filter); the
+  // entries it keeps out of the lists are the ones the statistics build saw die at once
+  const double own = (double)std::max<unsigned long long>(cnt[7], 1);
+  if (p->tab.ovf_dir && (double)cnt[5] / own >= 0.02 && !getenv("RX_NO_PRUNE")) {
+    const double entries = active * (1.0 - (double)cnt[6] / own);
+    if (entries <= 6.0) {
+      const uint32_t lanes = lanes_for(entries);
+      if ((rc = run(lanes, false, true, &spilled))) return rc;
+      if (spilled <= 0.02) { p->auto_lanes = lanes; p->auto_prune = true; return RX_OK; }
+    }
+    if ((rc = run(4, false, true, &spilled))) return rc;
+    if (spilled <= 0.02) { p->auto_lanes = 4; p->auto_prune = true; return RX_OK; }
+  }
+  if (active <= 6.0 && spilled16 <= 0.02) {
+    p->auto_lanes = lanes_for(active);
     return RX_OK;
   }
-  // many active states per stream (rule sets): four streams per wavefront with the long list (512 entries) and
-  // the wider filters, if that form keeps (nearly) all of the sample; otherwise one wavefront per stream
-  if ((rc = run(4, &active, &spilled))) return rc;
+  // many active states per stream: four streams per wavefront with the long list (512 entries) and the wider
+  // filters, if that form keeps (nearly) all of the sample; otherwise one wavefront per stream
+  if ((rc = run(4, true, false, &spilled))) return rc;
   if (spilled <= 0.02) p->auto_lanes = 4;
   else p->auto_kernel = RX_KERNEL_SYM_WAVE;
   return RX_OK;
@@ -620,6 +649,10 @@ extern "C" int rx_plan_launch(rx_plan* p) {
   rc = rx_pick_launch(kernel, h.size, a.n_streams, p->tab.cu_count, p->tab.lds_per_cu, &a, &p->cfg);
   if (rc) return rc;
   p->cfg.stats = p->opts.collect_stats != 0;
+  // look-ahead pruning of multi-target rows: AUTO follows its probe; an explicit RX_KERNEL_SYM_PACK uses it whenever
+  // the automaton has such rows (RX_NO_PRUNE=1 switches it off for A/B measurements and tests)
+  p->cfg.prune = p->tab.ovf_dir != nullptr && !getenv("RX_NO_PRUNE") &&
+                 (p->opts.kernel == RX_KERNEL_SYM_PACK || (p->opts.kernel == RX_KERNEL_AUTO && p->auto_prune));
   const bool two_tier = p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK ||
                         p->cfg.kernel == RX_KERNEL_DFA;
   if (two_tier && (rc = ensure_spill_area(p, a))) return rc;

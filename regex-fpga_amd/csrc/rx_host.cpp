@@ -225,5 +225,58 @@ int rxh_build(const uint32_t* W, size_t nwords, uint32_t size_or_0, RxHostNfa* o
       for (uint32_t k = 0; k < out->n_classes; k++)
         out->symidx_c[(size_t)i * out->n_classes + k] = out->symidx[(size_t)i * 256 + rep[k]];
   }
+  // ---- look-ahead pruning of multi-target rows (pack kernel) -------------------------------------------------
+  // A row with several targets on one byte (rule sets: every pattern that starts with that byte) activates states
+  // most of which die on the very next byte.  A state that is not an accept state and has no edge on the next byte
+  // cannot produce a pulse or a successor, so the pack kernel may skip inserting it — provided the sets it reports
+  // (final sets, hand-off rows after the stream's last byte) are built from the full lists.  Per primary list and
+  // per class of the NEXT byte the surviving targets are precomputed here as ordinary (interned) overflow lists.
+  out->symidx_p.clear();
+  out->ovf_dir.clear();
+  {
+    const uint32_t ncls = out->n_classes;
+    std::map<uint32_t, uint32_t> list_no;  // overflow offset -> list number
+    for (uint32_t w : out->symidx_c)
+      if (w & RXE_OVF) list_no.emplace(w & RXE_TGT_MASK, 0u);
+    uint32_t n = 0;
+    for (auto& kv : list_no) kv.second = n++;
+    bool ok = n != 0 && (uint64_t)n * (ncls + 1u) <= (16u << 20);
+    if (ok) {
+      auto dir_word = [](uint32_t off, uint32_t cnt) { return (off << 8) | (cnt < 255u ? cnt : 255u); };
+      out->ovf_dir.assign((size_t)n * (ncls + 1u), 0u);
+      std::vector<uint32_t> sub;
+      for (auto& kv : list_no) {
+        const uint32_t off = kv.first, cnt = out->ovf[off];
+        uint32_t* dir = &out->ovf_dir[(size_t)kv.second * (ncls + 1u)];
+        dir[ncls] = dir_word(off, cnt);
+        for (uint32_t k = 0; k < ncls && ok; k++) {
+          sub.clear();
+          for (uint32_t j = 0; j < cnt; j++) {
+            const uint32_t t = out->ovf[off + 1u + j];
+            if ((t & RXE_ACCEPT) || out->symidx_c[(size_t)(t & RXE_TGT_MASK) * ncls + k] != 0u) sub.push_back(t & RXE_TGT_MASK);
+          }
+          if (sub.size() == cnt) { dir[k] = dir[ncls]; continue; }
+          if (sub.empty()) { dir[k] = 0u; continue; }
+          auto it = ovf_at.find(sub);  // sub-lists are ordinary lists: [count][targets with their flags]
+          if (it == ovf_at.end()) {
+            const size_t o2 = out->ovf.size();
+            if (o2 + sub.size() + 1 > RXE_TGT_MASK) { ok = false; break; }
+            out->ovf.push_back((uint32_t)sub.size());
+            for (uint32_t t : sub) out->ovf.push_back(t | (is_acc(t) ? RXE_ACCEPT : 0u) | pin_flag(t));
+            it = ovf_at.emplace(sub, (uint32_t)o2).first;
+          }
+          dir[k] = dir_word(it->second, (uint32_t)sub.size());
+        }
+        if (!ok) break;
+      }
+    }
+    if (ok) {
+      out->symidx_p = out->symidx_c;
+      for (uint32_t& w : out->symidx_p)
+        if (w & RXE_OVF) w = (w & ~RXE_TGT_MASK) | list_no[w & RXE_TGT_MASK];
+    } else {
+      out->ovf_dir.clear();
+    }
+  }
   return RX_OK;
 }

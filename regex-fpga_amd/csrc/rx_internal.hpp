@@ -34,6 +34,11 @@ struct RxParams {
   const uint32_t* words;
   const uint32_t* symidx;       // [size][256] slice index (null for the CSR kernel)
   const uint32_t* symidx_c;     // [size][n_classes] the same index per byte class (pack kernel)
+  // look-ahead pruning of multi-target rows (pack kernel, see rx_host.cpp): index whose RXE_OVF payload is a LIST
+  // NUMBER, and per list (n_classes + 1) directory words (ovf offset << 8 | min(count, 255)): entry c = the targets
+  // that survive a next byte of class c, entry n_classes = the full list.  Both null when there is nothing to prune.
+  const uint32_t* symidx_p;
+  const uint32_t* ovf_dir;
   const uint32_t* byte_class;   // [64] words = 256 bytes: class id of every input byte
   uint32_t n_classes;
   const uint32_t* ovf;          // overflow target lists of the slice index
@@ -55,6 +60,7 @@ struct RxParams {
   rx_event* events;
   uint32_t events_cap;
   unsigned long long* counters; // [0] n_events [1] sum_active [2] sum_edges [3] spilled streams [4] pair clock cost
+                                // pack statistics build: [5] entries on multi-target rows [6] of their targets, dead at once [7] its own active
   uint32_t* match_count;        // [n_streams][size] or null
   unsigned long long* match_count_total; // [size] or null
   uint32_t* anymatch;           // [n_streams][anymatch_stride] or null
@@ -96,6 +102,7 @@ struct RxLaunchCfg {
   uint32_t lds_bytes;      // dynamic LDS per block
   int cu_count;
   bool stats;
+  bool prune;              // SYM_PACK: look-ahead pruning of multi-target rows (needs RxParams::ovf_dir)
 };
 
 // rx_kernels.hip
@@ -118,6 +125,8 @@ struct RxHostNfa {
   // A state with a self-loop on all 256 bytes stays active forever once entered.  The one state 0 feeds on
   // the most bytes (snort_16: state 1, the `.*` state) is "pinned": targets equal to it carry RXE_PIN.
   uint32_t pin_state = 0xFFFFFFFFu;
+  // look-ahead pruning tables (RxParams::symidx_p / ovf_dir); empty when the automaton has no multi-target rows
+  std::vector<uint32_t> symidx_p, ovf_dir;
   const uint32_t* row_ptr() const { return words.data(); }
   const uint32_t* col() const { return words.data() + size + 1; }
 };

@@ -750,12 +750,14 @@ __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
 //   * filter bit already set => wave-parallel exact scan of the next list for that (stream,state);
 //   * lanes 0..S-1 additionally own one stream each for input refill and bitmap stores;
 //   * next list would exceed RX_PACK_CAP => all S streams are handed to the wave kernel (resume).
-template <int S>
+template <int S, bool PRUNE>
 struct PackLayout {
   // few streams per wavefront = automata/inputs with many active states per stream: longer list, wider filters
   static constexpr uint32_t FW = S <= 4 ? 2u * RX_GROUP_FILTER_WORDS : RX_GROUP_FILTER_WORDS;
   static constexpr uint32_t CAPW = S <= 4 ? 512u : RX_PACK_CAP;
-  static constexpr uint32_t WINW = 16;                      // 64 input bytes (as byte classes) per stream
+  // 64 input bytes (as byte classes) per stream; PRUNE: + byte 64 = first class of the next chunk (look-ahead at
+  // the window's last byte) + a pad word that keeps the stride odd
+  static constexpr uint32_t WINW = PRUNE ? 18 : 16;
   static constexpr uint32_t STRIDE = 2u * FW + WINW + 1u;   // + any-match word; odd => banks spread
   static constexpr uint32_t LISTW = CAPW + 128u;            // a sweep appends at most 128 entries past CAPW: no bounds check
   static constexpr uint32_t WAVE_WORDS = 2u * LISTW + S * STRIDE + S;  // lists, stream regions, spill slots
@@ -764,8 +766,14 @@ struct PackLayout {
 
 // PROF: diagnostic build only (RX_PROFILE_PACK=1): s_memtime stamps around the phases of a pass; the sums go to
 // counters[8..15], which nothing else reads.  Its run time is not representative — read the SHARES.
-template <int S, bool STATS, bool PROF>
+// PRUNE: look-ahead pruning (rx_host.cpp) — multi-target rows insert only the targets that survive the stream's NEXT
+// byte.  The statistics build counts every active state of the reference's sets, so it always runs unpruned; it marks
+// the entries that came out of multi-target rows (bit 29) and counts those that die at once, which is what AUTO
+// needs to know to pick PRUNE and the streams per wavefront that go with it.
+template <int S, bool STATS, bool PROF, bool PRUNE>
 __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
+  static_assert(!(PRUNE && (STATS || PROF)), "statistics / stamped builds run unpruned");
+  constexpr uint32_t MARK = 1u << 29;  // STATS only: entry was inserted from a multi-target row
   unsigned long long t_prev = 0, t_sum[7] = {0, 0, 0, 0, 0, 0, 0};
   auto stamp = [&](int phase) {
     if (PROF) {
@@ -775,7 +783,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       t_prev = t;
     }
   };
-  using L = PackLayout<S>;
+  using L = PackLayout<S, PRUNE>;
   constexpr uint32_t HMASK = 32u * L::FW - 1u;
   constexpr uint32_t SID_SHIFT = 24, SID_MASK = 31u << SID_SHIFT;
   constexpr uint32_t KEY_MASK = RXE_TGT_MASK | SID_MASK;
@@ -788,10 +796,11 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
   uint32_t* sreg0 = wl + 2u * L::LISTW;              // [S][STRIDE]: filters[2][FW], window[WINW], am word
   uint32_t* slotw = sreg0 + S * L::STRIDE;           // [S] spill slots
   const uint32_t* __restrict__ rp = p.words;
-  const uint32_t* __restrict__ symidx = p.symidx_c;
+  constexpr bool prune = PRUNE;
+  const uint32_t* __restrict__ symidx = PRUNE ? p.symidx_p : p.symidx_c;
   const uint32_t ncls = p.n_classes;
   const uint32_t* __restrict__ ovf = p.ovf;
-  unsigned long long st_active = 0, st_edges = 0, st_cost = 0;
+  unsigned long long st_active = 0, st_edges = 0, st_cost = 0, st_ovf = 0, st_dead = 0;
 
   for (uint32_t w = threadIdx.x; w < L::CMAPW; w += blockDim.x) cmapw[w] = p.byte_class[w];
   __syncthreads();  // the only block-wide barrier; the waves never meet again
@@ -872,6 +881,16 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       *am = 0u;
     }
     wave_sync();
+  };
+
+  // PRUNE: class of the first byte of the NEXT chunk (already requested, in `nxt`) behind the window, so that the
+  // look-ahead also works at the window's last byte; called in the middle of a chunk, when that load has landed
+  auto stash_next_first = [&]() {
+#pragma unroll
+    for (uint32_t g = 0; g < NLOAD; g++) {
+      const uint32_t slot = g * 16u + (lane >> 2);
+      if ((lane & 3u) == 0u && slot < n_mine) sreg0[slot * L::STRIDE + 2u * L::FW + 16u] = cmap[nxt[g][0] & 0xFFu];
+    }
   };
 
   // One pass (FPGA.v:158-741 for S streams).  `consume` is a compile-time tag: the passes that take an input byte are
@@ -971,12 +990,17 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       uint32_t x = x_none;
       if (live)  // s < 2^24, ncls <= 256: the 24-bit multiply-add is a full-rate VALU op, v_mul_lo_u32 is quarter rate
         x = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(symidx) + ((__umul24(s, ncls) + c) << 2));
+      if (STATS) {
+        if (x & RXE_OVF) st_ovf += 1;
+        if ((e & MARK) && live && x == 0u) st_dead += 1;  // came out of a multi-target row and dies at once
+      }
+      const uint32_t e_keep = STATS ? e & ~MARK : e;
       if (PROF) { asm volatile("" ::"v"(x)); stamp(2); }  // phase 2: slice gather
       // two candidates per lane: the state itself (self-loop) and the inline target.  Both filter atomics are issued
       // by every lane, back to back, with one wait: a lane without a candidate ORs 0 (a no-op) into the word its
       // hash names anyway instead of sitting out in a branch or selecting another address.
       constexpr uint32_t T1_MASK = RXE_TGT_MASK | RXE_ACCEPT;
-      const uint32_t t1 = (x & T1_MASK) | (e & ~T1_MASK);  // v_bfi: a live e has only its slot bits outside the mask
+      const uint32_t t1 = (x & T1_MASK) | (e_keep & ~T1_MASK);  // v_bfi: a live e has only its slot bits outside the mask
       const uint32_t h0 = e & HMASK, h1 = x & HMASK;
       const uint32_t v0 = (x & RXE_SELF) ? 1u << (h0 & 31u) : 0u;    // bit to set, 0 = no candidate
       const uint32_t v1 = (x & RXE_INLINE) ? 1u << (h1 & 31u) : 0u;
@@ -987,13 +1011,13 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       // fresh: candidate whose bit was clear; maybe: candidate whose bit was already set
       const uint64_t mf0 = wballot((v0 & ~o0) != 0u), mf1 = wballot((v1 & ~o1) != 0u);
       if (Nn <= L::CAPW) {  // (wave-uniform) past that the pass ends in a hand-off anyway; keeps writes inside LISTW
-        if ((v0 & ~o0) != 0u) nlist[rank_below_plus(mf0, Nn)] = e;
+        if ((v0 & ~o0) != 0u) nlist[rank_below_plus(mf0, Nn)] = e_keep;
         if ((v1 & ~o1) != 0u) nlist[rank_below_plus(mf1, Nn + (uint32_t)__popcll(mf0))] = t1;
       }
       Nn += (uint32_t)__popcll(mf0) + (uint32_t)__popcll(mf1);
       if (wballot(((v0 & o0) | (v1 & o1)) != 0u)) {  // rare
         wave_sync();
-        resolve((v0 & o0) != 0u, e);
+        resolve((v0 & o0) != 0u, e_keep);
         resolve((v1 & o1) != 0u, t1);
       }
       stamp(4);  // phase 4: ballots, slots, list writes, rare duplicate resolution
@@ -1002,18 +1026,30 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       // hands every entry its lane range), then ONE sweep loads and inserts them all
       uint64_t mo = wballot(x & RXE_OVF);
       if (__builtin_expect(mo != 0, 0)) {
-        const uint32_t mycnt = (x & RXE_OVF) ? ovf[x & RXE_TGT_MASK] : 0u;
+        uint32_t myoff = x & RXE_TGT_MASK, mycnt = 0u;  // this lane's list: ovf[myoff] = count, targets behind it
+        if (prune) {
+          // directory entry for the class of the stream's next byte; the full list when the sets built now are the
+          // ones reported (the stream's last byte)
+          uint32_t sel = ncls;
+          if (k + 1u < p.n_consume) sel = reinterpret_cast<const uint8_t*>(sreg + 2u * L::FW)[kk + 1u];  // byte 64: stash
+          const uint32_t d = (x & RXE_OVF) ? p.ovf_dir[(x & RXE_TGT_MASK) * (ncls + 1u) + sel] : 0u;
+          myoff = d >> 8;
+          mycnt = d & 255u;
+          if (mycnt == 255u) mycnt = ovf[myoff];
+        } else if (x & RXE_OVF) {
+          mycnt = ovf[myoff];
+        }
         uint32_t total = 0, my_at = 0, my_sid = 0;
         auto flush = [&]() {
           const bool act = lane < total;
           const uint32_t w = act ? ovf[my_at] : 0u;
-          insert(act, (w & (RXE_TGT_MASK | RXE_ACCEPT)) | (my_sid << SID_SHIFT), sreg0 + my_sid * L::STRIDE);
+          insert(act, (w & (RXE_TGT_MASK | RXE_ACCEPT)) | (my_sid << SID_SHIFT) | (STATS ? MARK : 0u), sreg0 + my_sid * L::STRIDE);
           total = 0;
         };
         do {
           const uint32_t src = (uint32_t)__builtin_ctzll(mo);
           mo &= mo - 1;
-          const uint32_t off = bcast(x & RXE_TGT_MASK, src);
+          const uint32_t off = bcast(myoff, src);
           const uint32_t osid = bcast(sid, src);
           const uint32_t cnt = bcast(mycnt, src);
           if (total != 0 && total + cnt > 64u) flush();
@@ -1022,7 +1058,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
             for (uint32_t q0 = 0; q0 < cnt; q0 += 64u) {
               const bool act = q0 + lane < cnt;
               const uint32_t w = act ? ovf[off + 1u + q0 + lane] : 0u;
-              insert(act, (w & (RXE_TGT_MASK | RXE_ACCEPT)) | (osid << SID_SHIFT), oreg);
+              insert(act, (w & (RXE_TGT_MASK | RXE_ACCEPT)) | (osid << SID_SHIFT) | (STATS ? MARK : 0u), oreg);
             }
           } else {
             const uint32_t d = lane - total;  // lanes [total, total+cnt) take this entry's targets
@@ -1086,6 +1122,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
         k++;
       } while (k < k32 && !spilled);
       if (!spilled && p.anymatch && (k & 31u) == 0u) store_anymatch((k >> 5) - 1u);
+      if (PRUNE && (k & 63u) == 32u) stash_next_first();
     }
   }
   while (k < p.n_passes && !spilled) {  // RX_MODE_FULL: pass N
@@ -1109,6 +1146,9 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
     if (st_active) atomicAdd(&p.counters[1], st_active);
     if (st_edges) atomicAdd(&p.counters[2], st_edges);
     if (st_cost) atomicAdd(&p.counters[4], st_cost);
+    if (st_ovf) atomicAdd(&p.counters[5], st_ovf);    // entries that met a multi-target row
+    if (st_dead) atomicAdd(&p.counters[6], st_dead);  // entries out of such rows that died on the next byte
+    if (st_active) atomicAdd(&p.counters[7], st_active);  // this kernel's share of counters[1]
   }
 }
 
@@ -1455,17 +1495,25 @@ static int launch_group(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s
                    : launch_one(rx_sym_group_kernel<G, false>, p, grid ? grid : 1, wpb * 64u, lds, s);
 }
 
-template <int S>
-static int launch_pack(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s) {
-  using L = PackLayout<S>;
+template <int S, bool PRUNE>
+static int launch_pack_as(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s) {
+  using L = PackLayout<S, PRUNE>;
   const uint32_t wpb = 4;
   const uint32_t waves = (p.n_streams + S - 1) / S;
   const uint32_t grid = (waves + wpb - 1) / wpb;
+  const uint32_t g = grid ? grid : 1;
   const uint32_t lds = (L::CMAPW + wpb * L::WAVE_WORDS) * 4u;
+  if (PRUNE) return launch_one(rx_sym_pack_kernel<S, false, false, true>, p, g, wpb * 64u, lds, s);
+  if (cfg.stats) return launch_one(rx_sym_pack_kernel<S, true, false, false>, p, g, wpb * 64u, lds, s);
   if (S == 16 && getenv("RX_PROFILE_PACK"))  // stamped diagnostic build, see the kernel's PROF note
-    return launch_one(rx_sym_pack_kernel<16, false, true>, p, grid ? grid : 1, wpb * 64u, lds, s);
-  return cfg.stats ? launch_one(rx_sym_pack_kernel<S, true, false>, p, grid ? grid : 1, wpb * 64u, lds, s)
-                   : launch_one(rx_sym_pack_kernel<S, false, false>, p, grid ? grid : 1, wpb * 64u, lds, s);
+    return launch_one(rx_sym_pack_kernel<16, false, true, false>, p, g, wpb * 64u, lds, s);
+  return launch_one(rx_sym_pack_kernel<S, false, false, false>, p, g, wpb * 64u, lds, s);
+}
+
+template <int S>
+static int launch_pack(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s) {
+  if (cfg.prune && !cfg.stats && p.ovf_dir) return launch_pack_as<S, true>(p, cfg, s);
+  return launch_pack_as<S, false>(p, cfg, s);
 }
 
 // returns a hipError_t value (0 = hipSuccess)

@@ -260,6 +260,39 @@ def test_automata_in_the_reference_convention(rx, orx, kernels):
             check_equal(rx, orx, got, ref, ("convention", trial, kern))
 
 
+def test_lookahead_pruning_of_multi_target_rows(rx, orx, automata, traces, gpu_nfas, monkeypatch):
+    """Pack kernel without statistics = the build that really runs: rows with several targets on one byte insert only
+    the targets that survive the stream's next byte (never at the stream's last byte).  Events, counts, bitmaps and
+    final sets must not depend on it (RX_NO_PRUNE=1 = the unpruned build), for stream lengths around the 64-byte
+    window edges and in both modes."""
+    cases = []
+    W, size = automata["l7"]                                          # a multi-target row in nearly every pass
+    for sl in (63, 64, 65, 129, 500):
+        cases.append(("l7", gpu_nfas["l7"], W, size,
+                      rx.workloads.trace_windows(traces[("l7", "lo")], traces[("l7", "hi")], 48, sl)))
+    pats = rx.workloads.synthetic_ruleset(120)
+    rs = rx.Nfa.compile(pats)
+    cases.append(("ruleset", rs, rs.words, rs.size, rx.workloads.ruleset_traffic(pats, 40, 700)))
+    rng = np.random.default_rng(4242)
+    for trial in range(25):
+        alpha = int(rng.integers(2, 6))
+        Wr, sz = random_nfa(rng, int(rng.integers(3, 300)), max_deg=int(rng.integers(4, 24)), alphabet=alpha,
+                            dense_rows=int(rng.integers(0, 3)))
+        cases.append((("random", trial), rx.Nfa.from_words(Wr, sz), Wr, sz,
+                      rng.integers(0, alpha, size=(int(rng.integers(1, 50)), int(rng.integers(0, 200))), dtype=np.uint8)))
+    for n, (name, nfa, Wc, sz, rows) in enumerate(cases):
+        mode = n & 1
+        ref = orx.match_batch(Wc, sz, rows, mode=mode, want_match_count=True, events_cap=1 << 22)
+        for lanes in (4, 8, 16, 32):
+            kern = dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=lanes)
+            got = rx.match(nfa, rows, mode=mode, **kern, want_match_count=True, events_cap=1 << 22)
+            check_equal(rx, orx, got, ref, ("pruned", name, lanes), stats=False)
+        monkeypatch.setenv("RX_NO_PRUNE", "1")
+        got = rx.match(nfa, rows, mode=mode, kernel=rx.KERNEL_SYM_PACK, group_lanes=16, want_match_count=True, events_cap=1 << 22)
+        monkeypatch.delenv("RX_NO_PRUNE")
+        check_equal(rx, orx, got, ref, ("unpruned", name), stats=False)
+
+
 def test_more_than_65536_states(rx, orx, kernels):
     """State ids above 16 bits: the pack kernel's list entries then keep the full 24-bit state field and take the
     byte class from the stream window (its WIDE build); every kernel must agree with the oracle there too."""
