@@ -565,11 +565,13 @@ static int auto_probe(rx_plan* p) {
   if (rc) return rc;
   const double active = (double)cnt[1] / units, spilled16 = spilled;
   p->probe_active = active;
-  // the pack kernel is fastest when one pass of a wavefront is ONE sweep with ~37 of the 64 lanes busy:
-  // streams per wavefront ~ 37 / (list entries per stream)   (snort_16: T 2.3 -> 16, U 1.15 -> 32)
+  // the pack kernel is fastest when one pass of a wavefront is ONE sweep with 30-37 of the 64 lanes busy:
+  // streams per wavefront ~ 33 / (list entries per stream)   (snort_16: T 2.3 -> 13, U 1.15 -> 32)
   auto lanes_for = [](double entries) {
-    static const uint32_t choices[] = {8, 12, 16, 20, 24, 32};
-    const double want = 37.0 / std::max(entries, 0.5);
+    // 13 and 22 = ceil(64 / 5) and ceil(64 / 3): at 65 536 streams on 1 024 SIMDs they fill every SIMD with the same
+    // number of wavefronts, like 16 (4) and 32 (2); measured optimum 13-16 for 2.3 entries per stream
+    static const uint32_t choices[] = {8, 11, 13, 16, 22, 24, 32};
+    const double want = 33.0 / std::max(entries, 0.5);
     uint32_t best = 16;
     double bd = 1e9;
     for (uint32_t c : choices) {

@@ -811,7 +811,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
   const uint32_t n_mine = p.n_streams - stream0 < (uint32_t)S ? p.n_streams - stream0 : (uint32_t)S;
   const bool owner = lane < n_mine;  // lane == stream slot it owns
   // input windows: lane = 4*slot + part fetches bytes [64*chunk + 16*part, +16) of stream `slot`
-  static_assert(S <= 16 || S % 4 == 0, "window loader covers 16 streams per wave-load");
+  static_assert(S >= 1 && S <= 32, "five-bit stream slot; the window loader covers 16 streams per wave-load");
   constexpr uint32_t NLOAD = (S + 15) / 16;  // wave-loads per refill
   auto load_win = [&](uint32_t chunk, uint32_t (&o)[NLOAD][4]) {
 #pragma unroll
@@ -1459,7 +1459,9 @@ int rx_pick_launch(uint32_t kernel, uint32_t size, uint32_t n_streams, int cu_co
   cfg->grid_blocks = blocks ? blocks : 1;
   if (kernel == RX_KERNEL_SYM_PACK) {
     const uint32_t gl = cfg->group_lanes;  // here: streams per wavefront
-    if (gl != 2 && gl != 4 && gl != 8 && gl != 12 && gl != 16 && gl != 20 && gl != 24 && gl != 32) cfg->group_lanes = 16;
+    if (gl != 2 && gl != 4 && gl != 8 && gl != 11 && gl != 12 && gl != 13 && gl != 16 && gl != 20 && gl != 22 && gl != 24 &&
+        gl != 32)
+      cfg->group_lanes = 16;
   }
   if (kernel == RX_KERNEL_SYM_GROUP) {
     const uint32_t gl = cfg->group_lanes;
@@ -1540,7 +1542,10 @@ int rx_launch(const RxParams& p, const RxLaunchCfg& cfg, void* hip_stream) {
         if (cfg.group_lanes == 2) e = launch_pack<2>(p, cfg, s);
         else if (cfg.group_lanes == 4) e = launch_pack<4>(p, cfg, s);
         else if (cfg.group_lanes == 8) e = launch_pack<8>(p, cfg, s);
+        else if (cfg.group_lanes == 11) e = launch_pack<11>(p, cfg, s);
         else if (cfg.group_lanes == 12) e = launch_pack<12>(p, cfg, s);
+        else if (cfg.group_lanes == 13) e = launch_pack<13>(p, cfg, s);
+        else if (cfg.group_lanes == 22) e = launch_pack<22>(p, cfg, s);
         else if (cfg.group_lanes == 20) e = launch_pack<20>(p, cfg, s);
         else if (cfg.group_lanes == 24) e = launch_pack<24>(p, cfg, s);
         else if (cfg.group_lanes == 32) e = launch_pack<32>(p, cfg, s);

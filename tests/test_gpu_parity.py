@@ -22,7 +22,7 @@ def kernels(rx):
             dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=1), dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=2),
             dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=4), dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=8),
             dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=16), dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=4),
-            dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=8),
+            dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=8), dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=13),
             dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=16), dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=24),
             dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=32), dict(kernel=rx.KERNEL_DFA), dict(kernel=rx.KERNEL_AUTO)]
 
