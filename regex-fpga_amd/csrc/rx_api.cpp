@@ -583,7 +583,14 @@ static int auto_probe(rx_plan* p) {
   // multi-target rows met by at least 2 % of the list entries: look-ahead pruning pays (rule sets, l7-filter); the
   // entries it keeps out of the lists are the ones the statistics build saw die at once
   const double own = (double)std::max<unsigned long long>(cnt[7], 1);
-  if (p->tab.ovf_dir && (double)cnt[5] / own >= 0.02 && !getenv("RX_NO_PRUNE")) {
+  const bool dbg = getenv("RX_DEBUG_AUTO") != nullptr;
+  if (dbg)
+    fprintf(stderr, "[rxmatch] probe: %.2f active states per stream-byte, hand-offs %.1f %%, %.1f %% of the entries on "
+                    "multi-target rows, %.1f %% of the entries dead on arrival from such rows\n",
+            active, 100.0 * spilled16, 100.0 * (double)cnt[5] / own, 100.0 * (double)cnt[6] / own);
+  // (pruning must remove at least a tenth of the entries to pay for its directory look-ups: l7-filter meets
+  // multi-target rows in every pass but nearly all of their targets live on)
+  if (p->tab.ovf_dir && (double)cnt[5] / own >= 0.02 && (double)cnt[6] / own >= 0.10 && !getenv("RX_NO_PRUNE")) {
     const double entries = active * (1.0 - (double)cnt[6] / own);
     if (entries <= 6.0) {
       const uint32_t lanes = lanes_for(entries);
@@ -639,6 +646,9 @@ extern "C" int rx_plan_launch(rx_plan* p) {
     if (!p->auto_decided) {
       if ((rc = auto_probe(p))) return rc;
       p->auto_decided = true;
+      if (getenv("RX_DEBUG_AUTO"))
+        fprintf(stderr, "[rxmatch] AUTO -> kernel %u, %u streams per wavefront, look-ahead pruning %s\n", p->auto_kernel,
+                p->auto_lanes, p->auto_prune ? "on" : "off");
     }
     kernel = p->auto_kernel;
     if (p->opts.group_lanes == 0 && kernel == RX_KERNEL_SYM_PACK) auto_lanes = p->auto_lanes;
