@@ -1039,6 +1039,14 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
         } else if (x & RXE_OVF) {
           mycnt = ovf[myoff];
         }
+        // lists of one (what pruning leaves of most multi-target rows): every such lane inserts its single target
+        // itself, all of them in one step; only longer lists go through the lane-range walk below
+        if (wballot(mycnt == 1u)) {
+          const bool one = mycnt == 1u;
+          const uint32_t w1 = one ? ovf[myoff + 1u] : 0u;
+          insert(one, (w1 & (RXE_TGT_MASK | RXE_ACCEPT)) | (sid << SID_SHIFT) | (STATS ? MARK : 0u), sreg);
+        }
+        mo = wballot(mycnt >= 2u);
         uint32_t total = 0, my_at = 0, my_sid = 0;
         auto flush = [&]() {
           const bool act = lane < total;
@@ -1046,7 +1054,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
           insert(act, (w & (RXE_TGT_MASK | RXE_ACCEPT)) | (my_sid << SID_SHIFT) | (STATS ? MARK : 0u), sreg0 + my_sid * L::STRIDE);
           total = 0;
         };
-        do {
+        while (mo) {
           const uint32_t src = (uint32_t)__builtin_ctzll(mo);
           mo &= mo - 1;
           const uint32_t off = bcast(myoff, src);
@@ -1065,7 +1073,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
             if (d < cnt) { my_at = off + 1u + d; my_sid = osid; }
             total += cnt;
           }
-        } while (mo);
+        }
         if (total != 0) flush();
       }
     }
