@@ -754,7 +754,8 @@ template <int S, bool PRUNE>
 struct PackLayout {
   // few streams per wavefront = automata/inputs with many active states per stream: longer list, wider filters
   static constexpr uint32_t FW = S <= 4 ? 2u * RX_GROUP_FILTER_WORDS : RX_GROUP_FILTER_WORDS;
-  static constexpr uint32_t CAPW = S <= 4 ? 512u : RX_PACK_CAP;
+  // (the PRUNE build serves automata with bursts of active states: twice the list for up to 13 streams per wavefront)
+  static constexpr uint32_t CAPW = S <= 4 ? 512u : (PRUNE && S <= 13 ? 2u * RX_PACK_CAP : RX_PACK_CAP);
   // 64 input bytes (as byte classes) per stream; PRUNE: + byte 64 = first class of the next chunk (look-ahead at
   // the window's last byte) + a pad word that keeps the stride odd
   static constexpr uint32_t WINW = PRUNE ? 18 : 16;
