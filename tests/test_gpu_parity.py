@@ -124,6 +124,8 @@ def test_synthetic_batches(rx, orx, automata, traces, gpu_nfas, kernels, workloa
     for kern in kernels:
         got = rx.match(gpu_nfas["snort_16"], rows, **kern, want_match_count=True, collect_stats=True)
         check_equal(rx, orx, got, ref, (workload, kern))
+        got = rx.match(gpu_nfas["snort_16"], rows, **kern, want_match_count=True)  # the build without statistics
+        check_equal(rx, orx, got, ref, (workload, kern, "plain"), stats=False)
 
 
 def test_ragged_and_edge_shapes(rx, orx, automata, traces, gpu_nfas, kernels):
@@ -138,6 +140,8 @@ def test_ragged_and_edge_shapes(rx, orx, automata, traces, gpu_nfas, kernels):
                 for kern in kernels:
                     got = rx.match(gpu_nfas["snort_16"], rows, mode=mode, **kern, collect_stats=True)
                     check_equal(rx, orx, got, ref, (sl, ns, mode, kern))
+                    got = rx.match(gpu_nfas["snort_16"], rows, mode=mode, **kern)
+                    check_equal(rx, orx, got, ref, (sl, ns, mode, kern, "plain"), stats=False)
     # strided view: rows start at odd addresses (stride 301, offset 1)
     buf = np.zeros(40 * 301 + 8, np.uint8)
     buf[:] = np.resize(hi[:5000], buf.size)
@@ -201,6 +205,8 @@ def test_active_set_larger_than_list_capacity(rx, orx, kernels):
     for kern in kernels:
         got = rx.match(nfa, rows, **kern, want_match_count=True, collect_stats=True)
         check_equal(rx, orx, got, ref, ("blowup", kern))
+        got = rx.match(nfa, rows, **kern, want_match_count=True)
+        check_equal(rx, orx, got, ref, ("blowup", kern, "plain"), stats=False)
 
 
 def test_handoff_in_the_middle_of_a_stream(rx, orx, kernels):
@@ -223,6 +229,8 @@ def test_handoff_in_the_middle_of_a_stream(rx, orx, kernels):
         for kern in kernels:
             got = rx.match(nfa, rows, mode=mode, want_match_count=True, collect_stats=True, **kern)
             check_equal(rx, orx, got, ref, ("late handoff", mode, kern))
+            got = rx.match(nfa, rows, mode=mode, want_match_count=True, **kern)
+            check_equal(rx, orx, got, ref, ("late handoff", mode, kern, "plain"), stats=False)
 
 
 def test_random_automata(rx, orx, kernels):
@@ -240,6 +248,8 @@ def test_random_automata(rx, orx, kernels):
         for kern in kernels:
             got = rx.match(nfa, rows, mode=mode, **kern, want_match_count=True, collect_stats=True)
             check_equal(rx, orx, got, ref, ("random", trial, kern))
+            got = rx.match(nfa, rows, mode=mode, **kern, want_match_count=True)
+            check_equal(rx, orx, got, ref, ("random", trial, kern, "plain"), stats=False)
 
 
 def test_automata_in_the_reference_convention(rx, orx, kernels):
@@ -258,6 +268,8 @@ def test_automata_in_the_reference_convention(rx, orx, kernels):
         for kern in kernels:
             got = rx.match(nfa, rows, mode=mode, **kern, want_match_count=True, collect_stats=True)
             check_equal(rx, orx, got, ref, ("convention", trial, kern))
+            got = rx.match(nfa, rows, mode=mode, **kern, want_match_count=True)
+            check_equal(rx, orx, got, ref, ("convention", trial, kern, "plain"), stats=False)
 
 
 def test_lookahead_pruning_of_multi_target_rows(rx, orx, automata, traces, gpu_nfas, monkeypatch):
@@ -390,6 +402,12 @@ def test_full_size_config3_properties(rx, orx, automata, traces, gpu_nfas, kerne
             assert np.array_equal(a[k], b[k]), k
         assert {k: v for k, v in a["stats"].items() if k in ("n_events", "sum_active", "sum_edges", "alg_bytes")} == \
                {k: v for k, v in b["stats"].items() if k in ("n_events", "sum_active", "sum_edges", "alg_bytes")}
+    # the builds that run when no statistics are asked for (what bench.py times), incl. AUTO's choice
+    for k in (dict(kernel=rx.KERNEL_AUTO), dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=13),
+              dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=16), dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=32)):
+        b = rx.match(gpu_nfas["snort_16"], rows, **k, events_cap=1 << 21)
+        for f in ("events", "match_count_total", "anymatch", "final_active"):
+            assert np.array_equal(a[f], b[f]), (k, f)
     ev = a["events"]
     assert a["n_events"] == len(ev) > 10000
     order = np.lexsort((ev["state"], ev["k"], ev["stream"]))
@@ -405,6 +423,35 @@ def test_full_size_config3_properties(rx, orx, automata, traces, gpu_nfas, kerne
     remap = np.searchsorted(pick, sel["stream"]).astype(np.uint32)
     sel = sel.copy()
     sel["stream"] = remap
+    assert np.array_equal(sel, ref["events"].astype(sel.dtype))
+    assert np.array_equal(a["final_active"][pick], ref["final_active"])
+    assert np.array_equal(a["anymatch"][pick], ref["anymatch"])
+
+
+def test_full_size_ruleset_standin(rx, orx):
+    """BASELINE configs[4] stand-in at bench size (compiled 10 396-state rule set, 16 384 x 4 KB): AUTO's choice
+    (pack kernel with look-ahead pruning) == the wavefront-per-stream kernel on every output, a seeded sample of
+    streams == the oracle, and the size-independent invariants hold."""
+    wl = rx.workloads
+    pats = wl.synthetic_ruleset()
+    nfa = rx.Nfa.compile(pats)
+    ns, sl = 16384, 4096
+    rows = wl.ruleset_traffic(pats, ns, sl)
+    a = rx.match(nfa, rows, kernel=rx.KERNEL_AUTO, events_cap=1 << 23)
+    assert rx.host.KERNEL_NAMES[a["stats"]["kernel_used"]] == "sym_pack" and not a["events_overflow"]
+    b = rx.match(nfa, rows, kernel=rx.KERNEL_SYM_WAVE, events_cap=1 << 23)
+    for f in ("events", "match_count_total", "anymatch", "final_active"):
+        assert np.array_equal(a[f], b[f]), f
+    ev = a["events"]
+    assert np.array_equal(np.bincount(ev["state"], minlength=nfa.size).astype(np.uint64), a["match_count_total"])
+    bits = np.zeros_like(a["anymatch"])
+    np.bitwise_or.at(bits, (ev["stream"], ev["k"] >> 5), (np.uint32(1) << (ev["k"] & 31)).astype(np.uint32))
+    assert np.array_equal(bits, a["anymatch"])
+    rng = np.random.default_rng(9)
+    pick = np.sort(rng.choice(ns, size=192, replace=False))
+    ref = orx.match_batch(nfa.words, nfa.size, rows[pick], events_cap=1 << 22)
+    sel = ev[np.isin(ev["stream"], pick)].copy()
+    sel["stream"] = np.searchsorted(pick, sel["stream"]).astype(np.uint32)
     assert np.array_equal(sel, ref["events"].astype(sel.dtype))
     assert np.array_equal(a["final_active"][pick], ref["final_active"])
     assert np.array_equal(a["anymatch"][pick], ref["anymatch"])
