@@ -268,7 +268,7 @@ def main():
             p2.close()
         out["kernels"] = extra
 
-    if not a.no_cpu_baseline:
+    if not a.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N=1 only (rank 0 is the only rank there)
         from oracle import orx  # checker / reported CPU baseline only
         W = nfa.words if a.workload == "R" else orx.load_coe(wl.L7_COE if a.workload == "L" else wl.SNORT_COE)
         size = nfa.size if a.workload == "R" else orx.infer_size(W)
