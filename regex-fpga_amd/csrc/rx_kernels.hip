@@ -952,7 +952,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       uint32_t* sreg = sreg0 + sid * L::STRIDE;
       {  // accept pulses
         const uint64_t ma = wballot((e & (E_NONE | RXE_ACCEPT)) == RXE_ACCEPT);
-        if (ma) {
+        if (__builtin_expect(ma != 0, 0)) {  // the common pass has no accept state: keep it the fall-through path
           const bool acc = (e & (E_NONE | RXE_ACCEPT)) == RXE_ACCEPT;
           uint32_t dummy = 0;
           emit_events(p, acc, s, stream0 + sid, k, lane, dummy);
@@ -1011,12 +1011,12 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       if (PROF) { asm volatile("" ::"v"(o0), "v"(o1)); stamp(3); }  // phase 3: the two filter atomics
       // fresh: candidate whose bit was clear; maybe: candidate whose bit was already set
       const uint64_t mf0 = wballot((v0 & ~o0) != 0u), mf1 = wballot((v1 & ~o1) != 0u);
-      if (Nn <= L::CAPW) {  // (wave-uniform) past that the pass ends in a hand-off anyway; keeps writes inside LISTW
+      if (__builtin_expect(Nn <= L::CAPW, 1)) {  // (wave-uniform) past that the pass ends in a hand-off anyway; keeps writes inside LISTW
         if ((v0 & ~o0) != 0u) nlist[rank_below_plus(mf0, Nn)] = e_keep;
         if ((v1 & ~o1) != 0u) nlist[rank_below_plus(mf1, Nn + (uint32_t)__popcll(mf0))] = t1;
       }
       Nn += (uint32_t)__popcll(mf0) + (uint32_t)__popcll(mf1);
-      if (wballot(((v0 & o0) | (v1 & o1)) != 0u)) {  // rare
+      if (__builtin_expect(wballot(((v0 & o0) | (v1 & o1)) != 0u) != 0, 0)) {  // rare
         wave_sync();
         resolve((v0 & o0) != 0u, e_keep);
         resolve((v1 & o1) != 0u, t1);
@@ -1081,7 +1081,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
 
     stamp(5);  // phase 5: overflow lists + loop control
     if (consume) {
-      if (Nn > L::CAPW) {
+      if (__builtin_expect(Nn > L::CAPW, 0)) {
         // the wave-wide list cannot hold the next sets: hand ALL of this wave's streams (S_k, k) to the
         // wave kernel.  S_k = the current list, still intact.
         unsigned long long b = 0;
