@@ -336,7 +336,8 @@ struct rx_plan {
   bool auto_decided = false;   // RX_KERNEL_AUTO: the probe has run for the current batch
   uint32_t auto_kernel = RX_KERNEL_SYM_PACK;
   uint32_t auto_lanes = 16;    // streams per wavefront chosen for the pack kernel
-  bool auto_prune = false;     // look-ahead pruning chosen by the probe
+  bool auto_prune = false;     // look-ahead pruning chosen (and verified at auto_lanes) by the probe
+  bool probe_prune = false;    // the probe's statistics say pruning pays (used when the caller fixes the kernel)
   double probe_active = 0;     // active states per stream-byte seen by the probe
   RxParams params{};
   RxLaunchCfg cfg{};
@@ -532,6 +533,7 @@ static int auto_probe(rx_plan* p) {
   p->auto_kernel = RX_KERNEL_SYM_PACK;
   p->auto_lanes = 16;
   p->auto_prune = false;
+  p->probe_prune = false;
   p->probe_active = 0;
   if (p->n_streams * p->stream_len < (256u << 10)) return RX_OK;  // tiny batch: not worth a probe
   // one run of the pack kernel with `lanes` streams per wavefront over the corner of the batch: the statistics
@@ -590,7 +592,8 @@ static int auto_probe(rx_plan* p) {
             active, 100.0 * spilled16, 100.0 * (double)cnt[5] / own, 100.0 * (double)cnt[6] / own);
   // (pruning must remove at least a tenth of the entries to pay for its directory look-ups: l7-filter meets
   // multi-target rows in every pass but nearly all of their targets live on)
-  if (p->tab.ovf_dir && (double)cnt[5] / own >= 0.02 && (double)cnt[6] / own >= 0.10 && !getenv("RX_NO_PRUNE")) {
+  p->probe_prune = p->tab.ovf_dir && (double)cnt[5] / own >= 0.02 && (double)cnt[6] / own >= 0.10;
+  if (p->probe_prune && !getenv("RX_NO_PRUNE")) {
     const double entries = active * (1.0 - (double)cnt[6] / own);
     if (entries <= 6.0) {
       const uint32_t lanes = lanes_for(entries);
@@ -642,7 +645,9 @@ extern "C" int rx_plan_launch(rx_plan* p) {
     kernel = RX_KERNEL_SYM_PACK;
   }
   a.pair_cycles = pair ? 1u : 0u;
-  if (kernel == RX_KERNEL_AUTO && !pair && !p->have_init) {
+  // the probe also serves an explicit RX_KERNEL_SYM_PACK: whether look-ahead pruning pays depends on the input
+  const bool probe_for_pack = kernel == RX_KERNEL_SYM_PACK && p->tab.ovf_dir && p->opts.collect_stats == 0;
+  if ((kernel == RX_KERNEL_AUTO || probe_for_pack) && !pair && !p->have_init) {
     if (!p->auto_decided) {
       if ((rc = auto_probe(p))) return rc;
       p->auto_decided = true;
@@ -650,8 +655,10 @@ extern "C" int rx_plan_launch(rx_plan* p) {
         fprintf(stderr, "[rxmatch] AUTO -> kernel %u, %u streams per wavefront, look-ahead pruning %s\n", p->auto_kernel,
                 p->auto_lanes, p->auto_prune ? "on" : "off");
     }
-    kernel = p->auto_kernel;
-    if (p->opts.group_lanes == 0 && kernel == RX_KERNEL_SYM_PACK) auto_lanes = p->auto_lanes;
+    if (kernel == RX_KERNEL_AUTO) {
+      kernel = p->auto_kernel;
+      if (p->opts.group_lanes == 0 && kernel == RX_KERNEL_SYM_PACK) auto_lanes = p->auto_lanes;
+    }
   }
   // a caller-supplied start set is a bitmask row: that is the wave kernel's dense form
   if (p->have_init && (kernel == RX_KERNEL_AUTO || kernel == RX_KERNEL_SYM_GROUP || kernel == RX_KERNEL_SYM_PACK ||
@@ -661,10 +668,12 @@ extern "C" int rx_plan_launch(rx_plan* p) {
   rc = rx_pick_launch(kernel, h.size, a.n_streams, p->tab.cu_count, p->tab.lds_per_cu, &a, &p->cfg);
   if (rc) return rc;
   p->cfg.stats = p->opts.collect_stats != 0;
-  // look-ahead pruning of multi-target rows: AUTO follows its probe; an explicit RX_KERNEL_SYM_PACK uses it whenever
-  // the automaton has such rows (RX_NO_PRUNE=1 switches it off for A/B measurements and tests)
+  // look-ahead pruning of multi-target rows follows the probe: AUTO's verified choice, or for an explicit
+  // RX_KERNEL_SYM_PACK what the probe's statistics say.  RX_NO_PRUNE=1 / RX_FORCE_PRUNE=1 override it (A/B
+  // measurements; tests, whose batches are too small for a probe).
   p->cfg.prune = p->tab.ovf_dir != nullptr && !getenv("RX_NO_PRUNE") &&
-                 (p->opts.kernel == RX_KERNEL_SYM_PACK || (p->opts.kernel == RX_KERNEL_AUTO && p->auto_prune));
+                 (getenv("RX_FORCE_PRUNE") != nullptr ||
+                  (p->opts.kernel == RX_KERNEL_SYM_PACK ? p->probe_prune : p->opts.kernel == RX_KERNEL_AUTO && p->auto_prune));
   const bool two_tier = p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK ||
                         p->cfg.kernel == RX_KERNEL_DFA;
   if (two_tier && (rc = ensure_spill_area(p, a))) return rc;

@@ -292,10 +292,11 @@ def test_lookahead_pruning_of_multi_target_rows(rx, orx, automata, traces, gpu_n
                             dense_rows=int(rng.integers(0, 3)))
         cases.append((("random", trial), rx.Nfa.from_words(Wr, sz), Wr, sz,
                       rng.integers(0, alpha, size=(int(rng.integers(1, 50)), int(rng.integers(0, 200))), dtype=np.uint8)))
+    monkeypatch.setenv("RX_FORCE_PRUNE", "1")  # these batches are too small for the probe that normally decides
     for n, (name, nfa, Wc, sz, rows) in enumerate(cases):
         mode = n & 1
         ref = orx.match_batch(Wc, sz, rows, mode=mode, want_match_count=True, events_cap=1 << 22)
-        for lanes in (4, 8, 16, 32):
+        for lanes in (4, 8, 13, 16, 32):
             kern = dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=lanes)
             got = rx.match(nfa, rows, mode=mode, **kern, want_match_count=True, events_cap=1 << 22)
             check_equal(rx, orx, got, ref, ("pruned", name, lanes), stats=False)
