@@ -40,7 +40,7 @@ int main(int argc, char** argv) {
   if (!coe || !lo || !hi) {
     fprintf(stderr,
             "usage: rx_report <table.coe> <input_trace_lo.mem> <input_trace_hi.mem>\n"
-            "                 [--size N] [--m-stop 200000] [--kernel 0..3] [--device D] [--full] [--events]\n");
+            "                 [--size N] [--m-stop 200000] [--kernel 0..5] [--device D] [--full] [--events]\n");
     return 2;
   }
   rx_nfa* nfa = nullptr;
