@@ -113,19 +113,20 @@ void rx_free(void* p);
 enum { RX_MODE_FULL = 0, RX_MODE_TB_COMPAT = 1 };
 
 enum {
-  RX_KERNEL_AUTO = 0,     /* probe, then choose: on the first launch for a batch the plan runs the pack
-                             kernel's statistics build over a corner of it (<= 512 streams x <= 1 KB; this
-                             synchronises the stream once) and picks RX_KERNEL_SYM_PACK for small active
-                             sets (<= 6 states per stream-byte; streams per wavefront ~ 37 / that number),
-                             RX_KERNEL_SYM_WAVE otherwise                                              */
+  RX_KERNEL_AUTO = 0,     /* probe, then choose: on the first launch for a batch (and again on every 32nd batch
+                             of the same shape) the plan runs the pack kernel's statistics build over a corner of
+                             it (<= 512 streams x <= 1 KB; this synchronises the stream) and picks
+                             RX_KERNEL_SYM_PACK — streams per wavefront ~ 33 / (list entries per stream), look-ahead
+                             pruning of multi-target rows when it removes >= 10 % of the entries — or, when even
+                             the long-list form of the pack kernel hands streams off, RX_KERNEL_SYM_WAVE         */
   RX_KERNEL_CSR_WAVE = 1, /* wavefront-per-stream over the state-major CSR exactly as loaded         */
   RX_KERNEL_SYM_WAVE = 2, /* wavefront-per-stream over the per-(state,symbol) slice index            */
   RX_KERNEL_SYM_GROUP = 3, /* G lanes per stream (64/G streams per wavefront), slice index;
                              rx_opts.group_lanes = G (1/2/4/8/16, default 4); streams whose active set
                              outgrows the group's list are finished by RX_KERNEL_SYM_WAVE in the same call */
   RX_KERNEL_SYM_PACK = 4  /* S streams per wavefront, the 64 lanes assigned dynamically to one wave-wide
-                             list of (stream,state) entries; rx_opts.group_lanes = S (8/12/16/20/24/32,
-                             default 16); same hand-off to RX_KERNEL_SYM_WAVE                         */
+                             list of (stream,state) entries; rx_opts.group_lanes = S (2/4/8/11/12/13/16/20/22/24/32,
+                             default 16; 2 and 4 use 512-entry lists); same hand-off to RX_KERNEL_SYM_WAVE */
   ,
   RX_KERNEL_DFA = 5       /* opt-in: lazy DFA, one LANE per stream and one table lookup per byte; the subset-
                              construction cache lives in HBM per automaton and device, is grown on the device

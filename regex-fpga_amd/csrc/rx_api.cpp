@@ -333,7 +333,8 @@ struct rx_plan {
   // current batch
   size_t n_streams = 0, stream_len = 0, stride = 0;
   bool have_input = false, launched = false;
-  bool auto_decided = false;   // RX_KERNEL_AUTO: the probe has run for the current batch
+  bool auto_decided = false;   // RX_KERNEL_AUTO: the probe's decision is valid for the current batch
+  uint32_t batches_since_probe = 0;
   uint32_t auto_kernel = RX_KERNEL_SYM_PACK;
   uint32_t auto_lanes = 16;    // streams per wavefront chosen for the pack kernel
   bool auto_prune = false;     // look-ahead pruning chosen (and verified at auto_lanes) by the probe
@@ -432,12 +433,18 @@ extern "C" void rx_plan_free(rx_plan* p) {
 static int set_batch(rx_plan* p, size_t n_streams, size_t stream_len, size_t stride) {
   if (n_streams == 0 || n_streams > p->max_streams || stream_len > p->max_len || stride < stream_len)
     return RX_EINVAL;
+  // AUTO's probe costs about as much as a launch: a plan that is fed batch after batch of the same shape (serving)
+  // keeps its decision and looks again every 32nd batch; a wrong guess only costs speed (hand-offs keep it exact)
+  const bool same_shape = p->have_input && p->n_streams == n_streams && p->stream_len == stream_len;
+  if (!same_shape || ++p->batches_since_probe >= 32) {
+    p->auto_decided = false;
+    p->batches_since_probe = 0;
+  }
   p->n_streams = n_streams;
   p->stream_len = stream_len;
   p->stride = stride;
   p->have_input = true;
   p->launched = false;
-  p->auto_decided = false;
   return RX_OK;
 }
 
