@@ -458,6 +458,19 @@ def test_full_size_ruleset_standin(rx, orx):
     assert np.array_equal(a["anymatch"][pick], ref["anymatch"])
 
 
+def test_automaton_too_large_for_lds_fails_loudly(rx):
+    """The wave kernels keep two size-bit bitmasks per stream in LDS (160 KB per CU): beyond ~650 000 states every
+    compute call must fail with RX_ECAPACITY (-8) instead of computing something else."""
+    size = 700_000
+    e = [(0, c, 1) for c in range(256)] + [(1, c, 1) for c in range(256)] + [(1, 97, 699_998), (699_998, 98, 699_999)]
+    nfa = rx.Nfa.from_words(build_words(size, e), size)
+    rows = np.frombuffer(b"xxabxx", np.uint8)
+    for kern in (dict(kernel=rx.KERNEL_AUTO), dict(kernel=rx.KERNEL_SYM_PACK), dict(kernel=rx.KERNEL_CSR_WAVE)):
+        with pytest.raises(rx.RxError) as err:
+            rx.match(nfa, rows, **kern)
+        assert err.value.code == -8, kern
+
+
 def test_sharded_entry_point_single_device(rx, orx, automata, traces, gpu_nfas):
     """rx_match_sharded with the one visible device listed twice: the partition/merge path of the C-ABI."""
     W, size = automata["snort_16"]
