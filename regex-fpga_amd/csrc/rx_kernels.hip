@@ -744,12 +744,16 @@ __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
 // (bits 28:24) next to the state id: lane L simply takes entry L, whatever stream it belongs to, so a
 // pass is one sweep of ceil(N/64) iterations with N = sum of the S active-set sizes (about 2.3 S).
 //   * per stream in LDS: two alternating 1024-bit hashed filters (insert through one, the entries
-//     that went through the other zero their word when processed), a 16-byte input window, one word
-//     of any-match bits;
+//     that went through the other zero their word when processed), a 64-byte window of the input's
+//     byte classes (one cooperative 16 B/lane wave-load per 64 passes), one word of any-match bits;
+//   * the slice index is stored per byte CLASS (bytes whose edges are the same in every state);
 //   * slots of the wave-wide next list come from __ballot + mbcnt (wave-level, scalar count);
 //   * filter bit already set => wave-parallel exact scan of the next list for that (stream,state);
-//   * lanes 0..S-1 additionally own one stream each for input refill and bitmap stores;
-//   * next list would exceed RX_PACK_CAP => all S streams are handed to the wave kernel (resume).
+//   * lanes 0..S-1 additionally own one stream each for bitmap stores and hand-off rows;
+//   * rows with several targets on the byte: lists laid side by side over the lanes, one sweep; PRUNE:
+//     only the targets that survive the stream's next byte;
+//   * next list would exceed the layout's CAPW => all S streams are handed to the wave kernel (resume);
+//   * the passes run in chunked loops (refill per 64, bitmap store per 32, mode as a compile-time tag).
 template <int S, bool PRUNE>
 struct PackLayout {
   // few streams per wavefront = automata/inputs with many active states per stream: longer list, wider filters
