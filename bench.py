@@ -248,6 +248,22 @@ def main():
                                  "accept_events_per_launch": ures["stats"]["n_events"]}
         up.close()
         del d_u
+        # BASELINE configs[1]: ONE shipped trace as ONE stream, tb-compat (a correctness config: a single stream is a
+        # single dependency chain, so this is latency, not throughput; the parity tests check its match vector)
+        one = traces[1][:200000].reshape(1, -1)
+        d_one = torch.from_numpy(one.copy()).to(dev)
+        sp = rx.Plan(nfa, 1, one.shape[1], mode=rx.MODE_TB_COMPAT, kernel=kern, device=local, stream=stream,
+                     events_cap=1 << 20, group_lanes=a.group_lanes)
+        sp.set_device_input(d_one.data_ptr(), 1, one.shape[1], one.shape[1], keepalive=d_one)
+        time_kernel(sp, 1)
+        savg, _, _ = time_kernel(sp, 2)
+        sres = sp.download()
+        out["single_stream_config1"] = {"input": "input_trace_hi_snort_16.mem, 200 000 B, tb-compat", "kernel_ms": round(savg, 3),
+                                        "mbit_s": round(8.0 * one.shape[1] / (savg * 1e-3) / 1e6, 2),
+                                        "accept_events": sres["stats"]["n_events"],
+                                        "kernel": rx.host.KERNEL_NAMES[sres["stats"]["kernel_used"]]}
+        sp.close()
+        del d_one
 
     if a.all_kernels:
         extra = {}
