@@ -580,11 +580,15 @@ static int auto_probe(rx_plan* p) {
   p->probe_active = active;
   // the pack kernel is fastest when one pass of a wavefront is ONE sweep with 30-37 of the 64 lanes busy:
   // streams per wavefront ~ 33 / (list entries per stream)   (snort_16: T 2.3 -> 13, U 1.15 -> 32)
-  auto lanes_for = [](double entries) {
+  // A batch that cannot give every SIMD at least two wavefronts at that size is latency-bound (a wavefront alone on
+  // its SIMD finishes a pass in ~1 100 cycles whatever it holds): then fewer streams per wavefront win
+  // (4 096 streams: S=4 0.52 ms, S=13 0.60 ms; 16 384 streams: S=8 0.61 ms, S=16 0.69 ms).
+  const double per_simd = (double)p->n_streams / (4.0 * std::max(p->tab.cu_count, 1));
+  auto lanes_for = [per_simd](double entries) {
     // 13 and 22 = ceil(64 / 5) and ceil(64 / 3): at 65 536 streams on 1 024 SIMDs they fill every SIMD with the same
     // number of wavefronts, like 16 (4) and 32 (2); measured optimum 13-16 for 2.3 entries per stream
-    static const uint32_t choices[] = {8, 11, 13, 16, 22, 24, 32};
-    const double want = 33.0 / std::max(entries, 0.5);
+    static const uint32_t choices[] = {4, 8, 11, 13, 16, 22, 24, 32};
+    const double want = std::min(33.0 / std::max(entries, 0.5), std::max(per_simd / 2.0, 4.0));
     uint32_t best = 16;
     double bd = 1e9;
     for (uint32_t c : choices) {
