@@ -25,6 +25,39 @@ int main(int argc, char** argv) {
   RxHostNfa h;
   CHECK(rxh_build(W.data(), W.size(), 0, &h) == RX_OK);
   CHECK(h.symidx.size() == (size_t)h.size * 256);
+  // invariants of the derived tables: the per-class index is the per-byte index read through the class map; the
+  // look-ahead directory keeps, per multi-target list and next-byte class, exactly the targets that are accept
+  // states or have an edge on that class, and its last entry is the full list
+  auto check_derived = [](const RxHostNfa& a) -> int {
+    const uint32_t ncls = a.n_classes;
+    CHECK(ncls >= 1 && ncls <= 256 && a.symidx_c.size() == (size_t)a.size * ncls);
+    for (uint32_t s = 0; s < a.size; s += (a.size > 4000 ? 7 : 1))
+      for (int c = 0; c < 256; c++) CHECK(a.symidx[(size_t)s * 256 + c] == a.symidx_c[(size_t)s * ncls + a.byte_class[c]]);
+    if (a.ovf_dir.empty()) { CHECK(a.symidx_p.empty()); return 0; }
+    CHECK(a.symidx_p.size() == a.symidx_c.size() && a.ovf_dir.size() % (ncls + 1u) == 0);
+    const uint32_t nlists = (uint32_t)(a.ovf_dir.size() / (ncls + 1u));
+    for (size_t i = 0; i < a.symidx_c.size(); i++) {
+      const uint32_t w = a.symidx_c[i], q = a.symidx_p[i];
+      if (!(w & RXE_OVF)) { CHECK(q == w); continue; }
+      CHECK((q & ~RXE_TGT_MASK) == (w & ~RXE_TGT_MASK) && (q & RXE_TGT_MASK) < nlists);
+      const uint32_t* dir = &a.ovf_dir[(size_t)(q & RXE_TGT_MASK) * (ncls + 1u)];
+      const uint32_t off = w & RXE_TGT_MASK, cnt = a.ovf[off];
+      CHECK((dir[ncls] >> 8) == off && (dir[ncls] & 255u) == (cnt < 255u ? cnt : 255u));
+      if (i % 13) continue;  // the per-class sub-lists of a sample of the entries
+      for (uint32_t k = 0; k < ncls; k++) {
+        std::vector<uint32_t> want;
+        for (uint32_t j = 0; j < cnt; j++) {
+          const uint32_t t = a.ovf[off + 1 + j];
+          if ((t & RXE_ACCEPT) || a.symidx_c[(size_t)(t & RXE_TGT_MASK) * ncls + k] != 0) want.push_back(t);
+        }
+        const uint32_t d = dir[k], o2 = d >> 8, c2 = (d & 255u) == 255u ? a.ovf[o2] : (d & 255u);
+        CHECK(c2 == want.size());
+        for (uint32_t j = 0; j < c2; j++) CHECK(a.ovf[o2 + 1 + j] == want[j]);
+      }
+    }
+    return 0;
+  };
+  CHECK(check_derived(h) == 0);
   std::string ttxt;
   CHECK(rxh_read_file(lo, &ttxt) == RX_OK);
   std::vector<uint8_t> blo;
@@ -43,6 +76,7 @@ int main(int argc, char** argv) {
   CHECK(rxc_compile(pats, 7, 0, &cw, &acc, &err) == RX_OK);
   RxHostNfa hc;
   CHECK(rxh_build(cw.data(), cw.size(), (uint32_t)acc.size(), &hc) == RX_OK);
+  CHECK(check_derived(hc) == 0);
   const char* badp[] = {"a**(", "[z-a]", "a{5,2}", "\\", "(", "a|*"};
   for (const char* b : badp) {
     const char* one[] = {b};
