@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define RX_ABI_VERSION 1
+#define RX_ABI_VERSION 2
 
 /* ---- error codes ------------------------------------------------------------------------ */
 enum {
@@ -140,12 +140,25 @@ typedef struct rx_opts {
   uint32_t mode;        /* RX_MODE_*                                                     */
   uint32_t kernel;      /* RX_KERNEL_*                                                   */
   void* stream;         /* hipStream_t to launch on; NULL = the default stream           */
-  uint64_t k_base;      /* added to every reported pass index (chunked streaming)        */
+  uint64_t k_base;      /* added to every reported pass index (chunked streaming).  rx_event.k is
+                           32 bits: k_base + passes of the batch must stay <= 2^32, else RX_EINVAL */
   uint32_t collect_stats; /* 1: also accumulate rx_stats.sum_active/sum_edges on the device;
                              2: additionally treat streams (2q, 2q+1) as Blk_Mem_tb's lock-step pair
                                 and predict its clock count -> rx_stats.tb_cycles (n_streams even)  */
   uint32_t group_lanes;   /* SYM_GROUP: lanes per stream; SYM_PACK: streams per wavefront; 0 = default */
+  uint32_t flags;         /* RX_OPT_* bits (ABI >= 2; a caller whose struct_size ends before this field gets 0) */
 } rx_opts;
+
+/* rx_opts.flags — A/B and diagnostic switches.  They are read when the plan is created, never from the
+ * environment and never on the launch path. */
+enum {
+  RX_OPT_NO_PRUNE = 1u,     /* SYM_PACK: never use look-ahead pruning of multi-target rows                       */
+  RX_OPT_FORCE_PRUNE = 2u,  /* SYM_PACK: always use it when the automaton has such rows (batches too small to probe) */
+  RX_OPT_VERBOSE = 4u,      /* print AUTO's probe figures / choice and the launch geometry to stderr               */
+  RX_OPT_PROFILE_PACK = 8u, /* SYM_PACK S=16: the s_memtime-stamped diagnostic build (phase shares on stderr)     */
+  RX_OPT_NO_FOLD = 16u,     /* SYM_PACK: never fold the always-on `.*` state out of the lists                     */
+  RX_OPT_FORCE_FOLD = 32u   /* SYM_PACK: fold it whenever the automaton has such a state                          */
+};
 
 /* One accept pulse: `state` was active and accepting in pass `k` of stream `stream`.
  * 12 bytes — the B_out event term of SURVEY.md §8(d). */

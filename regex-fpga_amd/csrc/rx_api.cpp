@@ -13,7 +13,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -36,6 +38,11 @@ static int hip_fail(hipError_t e, const char* what) {
     hipError_t e_ = (call);                                    \
     if (e_ != hipSuccess) return hip_fail(e_, #call);          \
   } while (0)
+
+// Nothing throws across the C boundary: allocation failures inside an entry point become RX_ENOMEM.
+#define RX_TRY try {
+#define RX_CATCH \
+  } catch (const std::bad_alloc&) { return RX_ENOMEM; } catch (...) { return RX_ENOMEM; }
 
 extern "C" const char* rx_strerror(int code) {
   switch (code) {
@@ -79,16 +86,18 @@ struct rx_nfa {
 };
 
 extern "C" int rx_nfa_from_words(const uint32_t* words, size_t nwords, uint32_t size_or_0, rx_nfa** out) {
+  RX_TRY
   if (!words || !out || nwords == 0) return RX_EINVAL;
-  rx_nfa* n = new (std::nothrow) rx_nfa();
-  if (!n) return RX_ENOMEM;
+  std::unique_ptr<rx_nfa> n(new rx_nfa());  // released on every error path, also when the index build throws
   int rc = rxh_build(words, nwords, size_or_0, &n->h);
-  if (rc) { delete n; return rc; }
-  *out = n;
+  if (rc) return rc;
+  *out = n.release();
   return RX_OK;
+  RX_CATCH
 }
 
 extern "C" int rx_nfa_load_coe(const char* path, uint32_t size_or_0, rx_nfa** out) {
+  RX_TRY
   if (!path || !out) return RX_EINVAL;
   std::string txt;
   int rc = rxh_read_file(path, &txt);
@@ -97,10 +106,12 @@ extern "C" int rx_nfa_load_coe(const char* path, uint32_t size_or_0, rx_nfa** ou
   rc = rxh_parse_coe_text(txt.data(), txt.size(), &w);
   if (rc) return rc;
   return rx_nfa_from_words(w.data(), w.size(), size_or_0, out);
+  RX_CATCH
 }
 
 extern "C" int rx_compile_patterns(const char* const* patterns, size_t n, uint32_t flags, rx_nfa** out, char* errbuf,
                                    size_t errbuf_len) {
+  RX_TRY
   if (!patterns || !out || n == 0) return RX_EINVAL;
   std::vector<uint32_t> words;
   std::vector<int32_t> acc;
@@ -112,20 +123,26 @@ extern "C" int rx_compile_patterns(const char* const* patterns, size_t n, uint32
   if (rc) return rc;
   (*out)->accept_pattern = std::move(acc);
   return RX_OK;
+  RX_CATCH
 }
 
 extern "C" int rx_nfa_accept_pattern(const rx_nfa* nfa, uint32_t state, int32_t* pattern_index) {
+  RX_TRY
   if (!nfa || !pattern_index || state >= nfa->h.size) return RX_EINVAL;
   *pattern_index = state < nfa->accept_pattern.size() ? nfa->accept_pattern[state] : -1;
   return RX_OK;
+  RX_CATCH
 }
 
 extern "C" int rx_nfa_save_coe(const rx_nfa* nfa, const char* path) {
+  RX_TRY
   if (!nfa || !path) return RX_EINVAL;
   return rxc_write_coe(path, nfa->h.words);
+  RX_CATCH
 }
 
 extern "C" int rx_nfa_get_info(const rx_nfa* nfa, rx_nfa_info* info) {
+  RX_TRY
   if (!nfa || !info) return RX_EINVAL;
   info->size = nfa->h.size;
   info->nnz = nfa->h.nnz;
@@ -134,6 +151,7 @@ extern "C" int rx_nfa_get_info(const rx_nfa* nfa, rx_nfa_info* info) {
   info->max_degree = nfa->h.max_degree;
   info->n_bitmask_words64 = (nfa->h.size + 63u) / 64u;
   return RX_OK;
+  RX_CATCH
 }
 
 extern "C" const uint32_t* rx_nfa_words(const rx_nfa* nfa, size_t* nwords) {
@@ -166,6 +184,7 @@ extern "C" void rx_nfa_free(rx_nfa* nfa) {
 }
 
 extern "C" int rx_trace_load_mem(const char* path, uint8_t** bytes, size_t* n) {
+  RX_TRY
   if (!path || !bytes || !n) return RX_EINVAL;
   std::string txt;
   int rc = rxh_read_file(path, &txt);
@@ -179,21 +198,26 @@ extern "C" int rx_trace_load_mem(const char* path, uint8_t** bytes, size_t* n) {
   *bytes = o;
   *n = b.size();
   return RX_OK;
+  RX_CATCH
 }
 extern "C" void rx_free(void* p) { free(p); }
 
 extern "C" int rx_device_count(int* n) {
+  RX_TRY
   if (!n) return RX_EINVAL;
   *n = 0;
   HIPCHK(hipGetDeviceCount(n));
   return RX_OK;
+  RX_CATCH
 }
 extern "C" int rx_device_name(int device, char* buf, size_t buflen) {
+  RX_TRY
   if (!buf || buflen == 0) return RX_EINVAL;
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device));
   snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
   return RX_OK;
+  RX_CATCH
 }
 
 template <typename T>
@@ -274,6 +298,7 @@ static int ensure_dfa_tables(const rx_nfa* cnfa, int device, DevTables* out) {
 }
 
 extern "C" int rx_nfa_dfa_info(const rx_nfa* cnfa, int device, uint64_t* n_states, uint64_t* n_transitions) {
+  RX_TRY
   if (!cnfa) return RX_EINVAL;
   rx_nfa* nfa = const_cast<rx_nfa*>(cnfa);
   std::lock_guard<std::mutex> lk(nfa->mu);
@@ -290,9 +315,11 @@ extern "C" int rx_nfa_dfa_info(const rx_nfa* cnfa, int device, uint64_t* n_state
   if (n_states) *n_states = hdr[2];
   if (n_transitions) *n_transitions = hdr[3];
   return RX_OK;
+  RX_CATCH
 }
 
 extern "C" int rx_nfa_dfa_reset(const rx_nfa* cnfa, int device) {
+  RX_TRY
   if (!cnfa) return RX_EINVAL;
   rx_nfa* nfa = const_cast<rx_nfa*>(cnfa);
   std::lock_guard<std::mutex> lk(nfa->mu);
@@ -305,6 +332,7 @@ extern "C" int rx_nfa_dfa_reset(const rx_nfa* cnfa, int device) {
   int rc = dfa_init_tables(nfa, it->second);
   if (prev >= 0) (void)hipSetDevice(prev);
   return rc;
+  RX_CATCH
 }
 
 // ---- plan -----------------------------------------------------------------------------------------
@@ -327,7 +355,8 @@ struct rx_plan {
   uint32_t* d_am = nullptr;
   uint32_t* d_final = nullptr;
   uint32_t* d_init = nullptr;
-  bool have_init = false;
+  bool have_init = false;             // start sets belong to ONE batch: every new input clears the flag
+  std::vector<uint64_t> init_stage;   // host staging of the caller's start sets (tail bits masked)
   uint32_t *d_spill_streams = nullptr, *d_spill_k = nullptr, *d_spill_rows = nullptr;
   size_t am_stride = 0;
   // current batch
@@ -348,6 +377,17 @@ struct rx_plan {
   double last_ms = 0;
 };
 
+// rx_opts as the caller's version of the header laid it out: fields beyond its struct_size read as 0
+static rx_opts read_opts(const rx_opts* opts) {
+  rx_opts o{};
+  o.device = -1;
+  if (opts) {
+    const size_t have = opts->struct_size ? std::min<size_t>(opts->struct_size, sizeof(rx_opts)) : sizeof(rx_opts);
+    memcpy(&o, opts, have);
+  }
+  return o;
+}
+
 static uint64_t passes_for(size_t n, uint32_t mode) {
   if (mode == RX_MODE_TB_COMPAT) return n >= 1 ? n - 1 : 0;  // testbench_BLK_Mem.sv:71: $finish at m == N
   return (uint64_t)n + 1;
@@ -366,12 +406,14 @@ static int bind_device(int device, int* resolved) {
 extern "C" int rx_plan_create(const rx_nfa* nfa, const rx_opts* opts, size_t max_streams, size_t max_stream_len,
                               size_t events_cap, uint32_t want_match_count, uint32_t want_anymatch,
                               uint32_t want_final, rx_plan** out) {
+  RX_TRY
   if (!nfa || !out || max_streams == 0) return RX_EINVAL;
   if (max_streams > 0xFFFFFFFFull || max_stream_len > 0xFFFFFFF0ull || events_cap > 0xFFFFFFFFull)
     return RX_ECAPACITY;
-  rx_opts o{};
-  if (opts) o = *opts; else o.device = -1;
+  const rx_opts o = read_opts(opts);
   if (o.mode > RX_MODE_TB_COMPAT) return RX_EINVAL;
+  // rx_event.k and the kernels' pass counters are 32 bits wide: a chained stream may not run past 2^32 passes
+  if (o.k_base + passes_for(max_stream_len, RX_MODE_FULL) > (1ull << 32)) return RX_EINVAL;
   int ndev = 0;
   {
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -407,6 +449,7 @@ extern "C" int rx_plan_create(const rx_nfa* nfa, const rx_opts* opts, size_t max
 #undef PLCHK
   *out = p;
   return RX_OK;
+  RX_CATCH
 }
 
 extern "C" void rx_plan_free(rx_plan* p) {
@@ -445,11 +488,13 @@ static int set_batch(rx_plan* p, size_t n_streams, size_t stream_len, size_t str
   p->stride = stride;
   p->have_input = true;
   p->launched = false;
+  p->have_init = false;  // a start set describes the batch it was given for (rx_plan_set_init_active comes AFTER the input)
   return RX_OK;
 }
 
 extern "C" int rx_plan_upload(rx_plan* p, const uint8_t* bytes, size_t n_streams, size_t stream_len,
                               size_t stride) {
+  RX_TRY
   if (!p || (!bytes && stream_len)) return RX_EINVAL;
   int dev;
   int rc = bind_device(p->device, &dev);
@@ -476,30 +521,52 @@ extern "C" int rx_plan_upload(rx_plan* p, const uint8_t* bytes, size_t n_streams
   p->d_in = p->d_in_own;
   p->stride = pitch;
   return RX_OK;
+  RX_CATCH
 }
 
 extern "C" int rx_plan_set_device_input(rx_plan* p, const void* device_bytes, size_t n_streams,
                                         size_t stream_len, size_t stride) {
+  RX_TRY
   if (!p || (!device_bytes && stream_len)) return RX_EINVAL;
   int rc = set_batch(p, n_streams, stream_len, stride);
   if (rc) return rc;
   p->d_in = (const uint8_t*)device_bytes;
   return RX_OK;
+  RX_CATCH
 }
 
 extern "C" int rx_plan_set_init_active(rx_plan* p, const uint64_t* init_active) {
+  RX_TRY
   if (!p) return RX_EINVAL;
   if (!init_active) { p->have_init = false; return RX_OK; }
   if (!p->have_input) return RX_ESTATE;
   int dev;
   int rc = bind_device(p->device, &dev);
   if (rc) return rc;
-  const size_t nw64 = ((size_t)p->nfa->h.size + 63) / 64;
-  if (!p->d_init) HIPCHK(hipMalloc((void**)&p->d_init, p->max_streams * nw64 * sizeof(uint64_t)));
-  HIPCHK(hipMemcpyAsync(p->d_init, init_active, p->n_streams * nw64 * sizeof(uint64_t), hipMemcpyHostToDevice,
+  const uint32_t size = p->nfa->h.size;
+  const size_t nw64 = ((size_t)size + 63) / 64;
+  if (!p->d_init) {
+    HIPCHK(hipMalloc((void**)&p->d_init, p->max_streams * nw64 * sizeof(uint64_t)));
+    HIPCHK(hipMemsetAsync(p->d_init, 0, p->max_streams * nw64 * sizeof(uint64_t), p->stream));
+  }
+  // Bits at or above `size` in a row's last word name states that do not exist (the kernels would index the
+  // tables with them): they are cleared in a staging copy, which also makes the call safe to return from — the
+  // caller's array is not read after this function returns.
+  try {
+    p->init_stage.assign(init_active, init_active + p->n_streams * nw64);
+  } catch (...) {
+    return RX_ENOMEM;
+  }
+  if (size & 63u) {
+    const uint64_t keep = (1ull << (size & 63u)) - 1ull;
+    for (size_t s = 0; s < p->n_streams; s++) p->init_stage[s * nw64 + nw64 - 1] &= keep;
+  }
+  HIPCHK(hipMemcpyAsync(p->d_init, p->init_stage.data(), p->n_streams * nw64 * sizeof(uint64_t), hipMemcpyHostToDevice,
                         p->stream));
+  HIPCHK(hipStreamSynchronize(p->stream));  // pageable staging memory: the copy has left it when this returns
   p->have_init = true;
   return RX_OK;
+  RX_CATCH
 }
 
 static void fill_common(rx_plan* p, RxParams& a) {
@@ -600,7 +667,7 @@ static int auto_probe(rx_plan* p) {
   // multi-target rows met by at least 2 % of the list entries: look-ahead pruning pays (rule sets, l7-filter); the
   // entries it keeps out of the lists are the ones the statistics build saw die at once
   const double own = (double)std::max<unsigned long long>(cnt[7], 1);
-  const bool dbg = getenv("RX_DEBUG_AUTO") != nullptr;
+  const bool dbg = (p->opts.flags & RX_OPT_VERBOSE) != 0;
   if (dbg)
     fprintf(stderr, "[rxmatch] probe: %.2f active states per stream-byte, hand-offs %.1f %%, %.1f %% of the entries on "
                     "multi-target rows, %.1f %% of the entries dead on arrival from such rows\n",
@@ -608,7 +675,7 @@ static int auto_probe(rx_plan* p) {
   // (pruning must remove at least a tenth of the entries to pay for its directory look-ups: l7-filter meets
   // multi-target rows in every pass but nearly all of their targets live on)
   p->probe_prune = p->tab.ovf_dir && (double)cnt[5] / own >= 0.02 && (double)cnt[6] / own >= 0.10;
-  if (p->probe_prune && !getenv("RX_NO_PRUNE")) {
+  if (p->probe_prune && !(p->opts.flags & RX_OPT_NO_PRUNE)) {
     const double entries = active * (1.0 - (double)cnt[6] / own);
     if (entries <= 6.0) {
       const uint32_t lanes = lanes_for(entries);
@@ -631,6 +698,7 @@ static int auto_probe(rx_plan* p) {
 }
 
 extern "C" int rx_plan_launch(rx_plan* p) {
+  RX_TRY
   if (!p) return RX_EINVAL;
   if (!p->have_input) return RX_ESTATE;
   int dev;
@@ -643,6 +711,7 @@ extern "C" int rx_plan_launch(rx_plan* p) {
   a.stream_len = (uint32_t)p->stream_len;
   a.n_passes = (uint32_t)passes_for(p->stream_len, p->opts.mode);
   a.n_consume = p->opts.mode == RX_MODE_TB_COMPAT ? a.n_passes : (uint32_t)p->stream_len;
+  if (p->opts.k_base + a.n_passes > (1ull << 32)) return RX_EINVAL;  // rx_event.k would wrap
   a.k_base = (uint32_t)p->opts.k_base;
   a.init_active = p->have_init ? p->d_init : nullptr;
   a.events = p->events_cap ? p->d_events : nullptr;
@@ -666,7 +735,7 @@ extern "C" int rx_plan_launch(rx_plan* p) {
     if (!p->auto_decided) {
       if ((rc = auto_probe(p))) return rc;
       p->auto_decided = true;
-      if (getenv("RX_DEBUG_AUTO"))
+      if (p->opts.flags & RX_OPT_VERBOSE)
         fprintf(stderr, "[rxmatch] AUTO -> kernel %u, %u streams per wavefront, look-ahead pruning %s\n", p->auto_kernel,
                 p->auto_lanes, p->auto_prune ? "on" : "off");
     }
@@ -683,11 +752,13 @@ extern "C" int rx_plan_launch(rx_plan* p) {
   rc = rx_pick_launch(kernel, h.size, a.n_streams, p->tab.cu_count, p->tab.lds_per_cu, &a, &p->cfg);
   if (rc) return rc;
   p->cfg.stats = p->opts.collect_stats != 0;
+  p->cfg.verbose = (p->opts.flags & RX_OPT_VERBOSE) != 0;
+  p->cfg.profile_pack = (p->opts.flags & RX_OPT_PROFILE_PACK) != 0;
   // look-ahead pruning of multi-target rows follows the probe: AUTO's verified choice, or for an explicit
-  // RX_KERNEL_SYM_PACK what the probe's statistics say.  RX_NO_PRUNE=1 / RX_FORCE_PRUNE=1 override it (A/B
-  // measurements; tests, whose batches are too small for a probe).
-  p->cfg.prune = p->tab.ovf_dir != nullptr && !getenv("RX_NO_PRUNE") &&
-                 (getenv("RX_FORCE_PRUNE") != nullptr ||
+  // RX_KERNEL_SYM_PACK what the probe's statistics say.  rx_opts.flags RX_OPT_NO_PRUNE / RX_OPT_FORCE_PRUNE override it
+  // (A/B measurements; tests, whose batches are too small for a probe).
+  p->cfg.prune = p->tab.ovf_dir != nullptr && !(p->opts.flags & RX_OPT_NO_PRUNE) &&
+                 ((p->opts.flags & RX_OPT_FORCE_PRUNE) != 0 ||
                   (p->opts.kernel == RX_KERNEL_SYM_PACK ? p->probe_prune : p->opts.kernel == RX_KERNEL_AUTO && p->auto_prune));
   const bool two_tier = p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK ||
                         p->cfg.kernel == RX_KERNEL_DFA;
@@ -724,10 +795,12 @@ extern "C" int rx_plan_launch(rx_plan* p) {
   p->n_timed++;
   p->launched = true;
   return RX_OK;
+  RX_CATCH
 }
 
 extern "C" int rx_plan_kernel_times(rx_plan* p, uint32_t* n_launches, double* sum_ms, double* min_ms,
                                     double* max_ms) {
+  RX_TRY
   if (!p) return RX_EINVAL;
   double sum = 0, mn = 0, mx = 0;
   for (size_t i = 0; i < p->n_timed; i++) {
@@ -744,9 +817,11 @@ extern "C" int rx_plan_kernel_times(rx_plan* p, uint32_t* n_launches, double* su
   if (max_ms) *max_ms = mx;
   p->n_timed = 0;
   return RX_OK;
+  RX_CATCH
 }
 
 extern "C" int rx_plan_sync(rx_plan* p, double* kernel_ms) {
+  RX_TRY
   if (!p) return RX_EINVAL;
   if (!p->launched) return RX_ESTATE;
   if (p->n_timed == 0) { if (kernel_ms) *kernel_ms = p->last_ms; return RX_OK; }
@@ -757,6 +832,7 @@ extern "C" int rx_plan_sync(rx_plan* p, double* kernel_ms) {
   p->last_ms = ms;
   if (kernel_ms) *kernel_ms = ms;
   return RX_OK;
+  RX_CATCH
 }
 
 static bool ev_less(const rx_event& a, const rx_event& b) {
@@ -766,6 +842,7 @@ static bool ev_less(const rx_event& a, const rx_event& b) {
 }
 
 extern "C" int rx_plan_download(rx_plan* p, rx_result* res) {
+  RX_TRY
   if (!p || !res) return RX_EINVAL;
   if (!p->launched) return RX_ESTATE;
   int dev;
@@ -778,7 +855,7 @@ extern "C" int rx_plan_download(rx_plan* p, rx_result* res) {
   HIPCHK(hipMemcpy(cnt, p->d_counters, sizeof(cnt), hipMemcpyDeviceToHost));
   rx_stats& st = res->stats;
   st = rx_stats{};
-  if (getenv("RX_PROFILE_PACK") && p->cfg.kernel == RX_KERNEL_SYM_PACK) {
+  if ((p->opts.flags & RX_OPT_PROFILE_PACK) && p->cfg.kernel == RX_KERNEL_SYM_PACK) {
     static const char* names[7] = {"list read", "accept check + window byte + filter clear", "slice gather", "filter atomics",
                                    "ballots + slots + list writes", "overflow lists", "end of pass"};
     unsigned long long tot = 0;
@@ -839,12 +916,15 @@ extern "C" int rx_plan_download(rx_plan* p, rx_result* res) {
                      hipMemcpyDeviceToHost));
   }
   return RX_OK;
+  RX_CATCH
 }
 
 // ---- one-shot -------------------------------------------------------------------------------------
 extern "C" int rx_match(const rx_nfa* nfa, const uint8_t* bytes, size_t n_streams, size_t stream_len, size_t stride,
                         const uint64_t* init_active, const rx_opts* opts, rx_result* res) {
+  RX_TRY
   if (!nfa || !res || (!bytes && stream_len) || n_streams == 0 || stride < stream_len) return RX_EINVAL;
+  if (read_opts(opts).k_base + passes_for(stream_len, RX_MODE_FULL) > (1ull << 32)) return RX_EINVAL;
   rx_plan* p = nullptr;
   int rc = rx_plan_create(nfa, opts, n_streams, stream_len, res->events ? res->events_cap : 0,
                           res->match_count != nullptr, res->anymatch != nullptr, res->final_active != nullptr, &p);
@@ -871,12 +951,14 @@ extern "C" int rx_match(const rx_nfa* nfa, const uint8_t* bytes, size_t n_stream
   res->stats.h2d_ms = h2d;
   res->stats.d2h_ms = std::chrono::duration<double, std::milli>(w1 - w0).count();
   return done(RX_OK);
+  RX_CATCH
 }
 
 // ---- multi-GPU: contiguous stream blocks, one host thread per device, no collective --------------
 extern "C" int rx_match_sharded(const rx_nfa* nfa, const uint8_t* bytes, size_t n_streams, size_t stream_len,
                                 size_t stride, const int* devices, int n_devices, const rx_opts* opts,
                                 rx_result* res) {
+  RX_TRY
   if (!nfa || !res || n_devices <= 0 || n_streams == 0 || stride < stream_len) return RX_EINVAL;
   const int nd = (int)std::min<size_t>((size_t)n_devices, n_streams);
   const uint32_t size = nfa->h.size;
@@ -901,8 +983,8 @@ extern "C" int rx_match_sharded(const rx_nfa* nfa, const uint8_t* bytes, size_t 
   for (int d = 0; d < nd; d++) {
     th.emplace_back([&, d]() {
       Shard& x = sh[d];
-      rx_opts o{};
-      if (opts) o = *opts;
+      rx_opts o = read_opts(opts);
+      o.struct_size = sizeof(rx_opts);
       o.device = devices ? devices[d] : d;
       o.stream = nullptr;  // a stream handle belongs to one device
       x.r = rx_result{};
@@ -949,6 +1031,8 @@ extern "C" int rx_match_sharded(const rx_nfa* nfa, const uint8_t* bytes, size_t 
     res->stats.d2h_ms = std::max(res->stats.d2h_ms, x.r.stats.d2h_ms);
     res->stats.kernel_used = x.r.stats.kernel_used;
     res->stats.n_launches += x.r.stats.n_launches;
+    res->stats.tb_cycles += x.r.stats.tb_cycles;  // pairs never straddle shards when every shard is even-sized
   }
   return RX_OK;
+  RX_CATCH
 }

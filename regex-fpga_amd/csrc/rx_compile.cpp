@@ -33,8 +33,13 @@ using ByteSet = std::bitset<256>;
 struct Node {
   enum Kind { CHAR, CAT, ALT, STAR, PLUS, OPT, EMPTY } kind = EMPTY;
   ByteSet cls;
+  uint32_t depth = 1;  // height of the subtree: parse, clone, walk and the destructor recurse this deep
   std::unique_ptr<Node> a, b;
 };
+// Recursion bound for everything that walks a tree (a few hundred bytes of stack per level).  Sequences and
+// alternations are built as balanced trees, so only real nesting — parentheses, {m,n} tails — counts.
+constexpr uint32_t RX_MAX_TREE_DEPTH = 2500;
+constexpr uint32_t RX_MAX_GROUP_NESTING = 250;
 using NodeP = std::unique_ptr<Node>;
 
 NodeP mk(Node::Kind k, NodeP a = nullptr, NodeP b = nullptr) {
@@ -42,6 +47,7 @@ NodeP mk(Node::Kind k, NodeP a = nullptr, NodeP b = nullptr) {
   n->kind = k;
   n->a = std::move(a);
   n->b = std::move(b);
+  n->depth = 1u + std::max(n->a ? n->a->depth : 0u, n->b ? n->b->depth : 0u);
   return n;
 }
 NodeP clone(const Node* n) {
@@ -49,6 +55,7 @@ NodeP clone(const Node* n) {
   NodeP c(new Node());
   c->kind = n->kind;
   c->cls = n->cls;
+  c->depth = n->depth;
   c->a = clone(n->a.get());
   c->b = clone(n->b.get());
   return c;
@@ -60,6 +67,7 @@ struct Parser {
   bool icase, dotall;
   std::string err;
   size_t budget = 200000;  // leaf budget (bounded repetition expands by copying)
+  uint32_t nesting = 0;    // open groups at the cursor
   Parser(const std::string& src, bool ic, bool da) : s(src), icase(ic), dotall(da) {}
 
   bool fail(const std::string& m) {
@@ -162,6 +170,19 @@ struct Parser {
     return true;
   }
 
+  // kind-tree over parts[lo, hi) of logarithmic height (a left-deep chain of an 80 000-byte literal would recurse
+  // 80 000 levels in clone / walk / ~Node)
+  NodeP balanced(Node::Kind kind, std::vector<NodeP>& parts, size_t lo, size_t hi) {
+    if (hi - lo == 1) return std::move(parts[lo]);
+    const size_t mid = lo + (hi - lo) / 2;
+    NodeP l = balanced(kind, parts, lo, mid), r = balanced(kind, parts, mid, hi);
+    return mk(kind, std::move(l), std::move(r));
+  }
+  NodeP checked(NodeP n) {
+    if (n && n->depth > RX_MAX_TREE_DEPTH) { fail("pattern nests too deeply"); return nullptr; }
+    return n;
+  }
+
   NodeP leaf(const ByteSet& c) {
     if (budget == 0) { fail("pattern expands to too many positions"); return nullptr; }
     budget--;
@@ -178,7 +199,9 @@ struct Parser {
         if (s[i + 1] == ':') i += 2;
         else { fail("unsupported group (?"); return nullptr; }
       }
+      if (++nesting > RX_MAX_GROUP_NESTING) { fail("groups nest too deeply"); return nullptr; }
       NodeP e = alt();
+      nesting--;
       if (!e) return nullptr;
       if (eof() || s[i] != ')') { fail("missing )"); return nullptr; }
       i++;
@@ -212,8 +235,8 @@ struct Parser {
     return leaf(fold(b));
   }
   NodeP repeat(NodeP a, int lo, int hi) {  // hi < 0: unbounded
-    NodeP out;
-    auto cat = [&](NodeP x) { out = out ? mk(Node::CAT, std::move(out), std::move(x)) : std::move(x); };
+    std::vector<NodeP> parts;
+    auto cat = [&](NodeP x) { parts.push_back(std::move(x)); };
     for (int k = 0; k < lo; k++) {
       NodeP c = clone(a.get());
       cat(std::move(c));
@@ -229,8 +252,8 @@ struct Parser {
       }
       if (tail) cat(std::move(tail));
     }
-    if (!out) out = mk(Node::EMPTY);
-    return out;
+    if (parts.empty()) return mk(Node::EMPTY);
+    return checked(balanced(Node::CAT, parts, 0, parts.size()));
   }
   size_t count_leaves(const Node* n) {
     if (!n) return 0;
@@ -241,9 +264,9 @@ struct Parser {
     if (!a) return nullptr;
     while (!eof()) {
       const char c = s[i];
-      if (c == '*') { i++; a = mk(Node::STAR, std::move(a)); }
-      else if (c == '+') { i++; a = mk(Node::PLUS, std::move(a)); }
-      else if (c == '?') { i++; a = mk(Node::OPT, std::move(a)); }
+      if (c == '*') { i++; a = checked(mk(Node::STAR, std::move(a))); }
+      else if (c == '+') { i++; a = checked(mk(Node::PLUS, std::move(a))); }
+      else if (c == '?') { i++; a = checked(mk(Node::OPT, std::move(a))); }
       else if (c == '{') {
         size_t j = i + 1;
         int lo = 0, hi = -2, nd = 0;
@@ -267,30 +290,33 @@ struct Parser {
         budget -= leaves * (copies ? copies - 1 : 0) > budget ? budget : leaves * (copies ? copies - 1 : 0);
         a = repeat(std::move(a), lo, hi);
       } else break;
+      if (!a) return nullptr;
       if (!eof() && (s[i] == '?' || s[i] == '+') && (c == '*' || c == '+' || c == '?' || c == '{')) i++;  // lazy/possessive: same language
     }
     return a;
   }
   NodeP seq() {
-    NodeP out;
+    std::vector<NodeP> parts;
     while (!eof() && s[i] != '|' && s[i] != ')') {
       NodeP p = piece();
       if (!p) return nullptr;
-      out = out ? mk(Node::CAT, std::move(out), std::move(p)) : std::move(p);
+      parts.push_back(std::move(p));
     }
-    if (!out) out = mk(Node::EMPTY);
-    return out;
+    if (parts.empty()) return mk(Node::EMPTY);
+    return checked(balanced(Node::CAT, parts, 0, parts.size()));
   }
   NodeP alt() {
+    std::vector<NodeP> parts;
     NodeP a = seq();
     if (!a) return nullptr;
+    parts.push_back(std::move(a));
     while (!eof() && s[i] == '|') {
       i++;
       NodeP b = seq();
       if (!b) return nullptr;
-      a = mk(Node::ALT, std::move(a), std::move(b));
+      parts.push_back(std::move(b));
     }
-    return a;
+    return checked(balanced(Node::ALT, parts, 0, parts.size()));
   }
 };
 

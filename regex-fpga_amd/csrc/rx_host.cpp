@@ -131,6 +131,7 @@ int rxh_build(const uint32_t* W, size_t nwords, uint32_t size_or_0, RxHostNfa* o
     int rc = rxh_validate(W, nwords, size);
     if (rc) return rc;
   }
+  if (size > RX_MAX_STATES) return RX_ECAPACITY;  // before the size*256-word index is allocated
   out->words.assign(W, W + nwords);
   out->size = size;
   out->nnz = W[size];

@@ -25,6 +25,9 @@ static constexpr uint32_t RXE_TGT_MASK = 0x00FFFFFFu;
 
 // Active-list entry (LDS): state id in bits 23:0, RXE_ACCEPT if the state is an accept state.
 
+// Every kernel keeps (or can fall back to) two size-bit bitmasks + two RX_LIST_CAP lists per stream in one CU's 160 KB
+// of LDS: 2*(size/8) + 1 KB <= 160 KB.  Larger automata are refused at load time, before any index is built.
+static constexpr uint32_t RX_MAX_STATES = 650000;
 static constexpr uint32_t RX_LIST_CAP = 128;  // sparse active-list capacity per stream (entries)
 static constexpr uint32_t RX_SMALL_DEG = 8;   // CSR kernel: rows up to this length are scanned per lane
 
@@ -103,6 +106,8 @@ struct RxLaunchCfg {
   int cu_count;
   bool stats;
   bool prune;              // SYM_PACK: look-ahead pruning of multi-target rows (needs RxParams::ovf_dir)
+  bool verbose;            // rx_opts.flags & RX_OPT_VERBOSE: print the launch geometry
+  bool profile_pack;       // rx_opts.flags & RX_OPT_PROFILE_PACK: stamped diagnostic build of the pack kernel (S=16)
 };
 
 // rx_kernels.hip

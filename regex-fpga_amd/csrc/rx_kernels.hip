@@ -5,7 +5,18 @@
 // (FPGA.v:744-765); here the active set is a compacted list per stream, so work is proportional
 // to |S_k|, and thousands of independent streams are resident at once.
 //
-// Execution model (both kernels): ONE WAVEFRONT (64 lanes) OWNS ONE INPUT STREAM.
+// Five kernels, one result (tests/test_gpu_parity.py compares every one of them with the oracle):
+//   rx_csr_wave_kernel   ONE WAVEFRONT OWNS ONE INPUT STREAM and reads the state-major CSR exactly as the .coe holds
+//                        it (row_ptr pair, then the whole row, as FPGA.v:166-207 / :227-714 do): long rows are swept
+//                        by all 64 lanes (256 B coalesced per load), short rows one lane per row.  North-star form.
+//   rx_sym_wave_kernel   one wavefront per stream over the load-time slice index: one u32 per (state, byte) that
+//                        holds "the current byte's slice" of that row (rx_internal.hpp).  Also the kernel that
+//                        finishes streams the three kernels below hand off (resume mode).
+//   rx_sym_group_kernel  G lanes per stream, 64/G streams per wavefront (static lane groups).
+//   rx_sym_pack_kernel   S streams per wavefront, the 64 lanes assigned dynamically to one wave-wide list of
+//                        (stream, state) entries — the throughput kernel RX_KERNEL_AUTO normally picks.
+//   rx_dfa_kernel        one LANE per stream over a lazily built subset-construction cache (opt-in).
+// Common to the two wave-per-stream kernels:
 //   * per-stream state lives in that wave's private LDS slice: two size-bit bitmasks (dedup
 //     filter for `next`, and the dense spill form of `current`) and two active-state lists;
 //   * the stream's bytes are fetched 256 B per wave-load (one dword per lane, coalesced) one
@@ -14,16 +25,9 @@
 //   * next-state insertion = ds_or_rtn_b32 on the bitmask (dedup) + __ballot/mbcnt/__popcll to
 //     allocate list slots and to flag accept states — no workgroup barrier anywhere: the four
 //     waves of a block never communicate;
-//   * no MFMA: this is integer gather / bit-scatter.
-//
-// rx_csr_wave_kernel  reads the state-major CSR exactly as the .coe holds it (row_ptr pair, then
-//                     the whole row, as FPGA.v:166-207 / :227-714 do): long rows are swept by all
-//                     64 lanes (256 B coalesced per load), short rows one lane per row.
-// rx_sym_wave_kernel  reads the load-time slice index instead: one u32 per (state, byte) that
-//                     holds "the current byte's slice" of that row (rx_internal.hpp).
-//
-// Active set larger than RX_LIST_CAP: the list stops growing but the bitmask keeps every bit, and
-// the next pass walks the bitmask instead ("dense" form).  Results are identical either way.
+//   * active set larger than RX_LIST_CAP: the list stops growing but the bitmask keeps every bit, and
+//     the next pass walks the bitmask instead ("dense" form).  Results are identical either way.
+// No MFMA anywhere: this is integer gather / bit-scatter.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -1483,6 +1487,8 @@ int rx_pick_launch(uint32_t kernel, uint32_t size, uint32_t n_streams, int cu_co
   return RX_OK;
 }
 
+static thread_local bool g_verbose = false;  // set per rx_launch call from RxLaunchCfg::verbose (rx_opts.flags)
+
 template <typename K>
 static int launch_one(K kern, const RxParams& p, uint32_t grid, uint32_t block, uint32_t lds, hipStream_t s) {
   if (lds > 64u * 1024u) {
@@ -1490,7 +1496,7 @@ static int launch_one(K kern, const RxParams& p, uint32_t grid, uint32_t block, 
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  if (getenv("RX_DEBUG_OCCUPANCY")) {
+  if (g_verbose) {
     int nb = 0;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, (int)block, lds);
     fprintf(stderr, "[rxmatch] grid %u x %u threads, %u B LDS/block -> %d blocks/CU resident\n", grid, block, lds, nb);
@@ -1520,7 +1526,7 @@ static int launch_pack_as(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t
   const uint32_t lds = (L::CMAPW + wpb * L::WAVE_WORDS) * 4u;
   if (PRUNE) return launch_one(rx_sym_pack_kernel<S, false, false, true>, p, g, wpb * 64u, lds, s);
   if (cfg.stats) return launch_one(rx_sym_pack_kernel<S, true, false, false>, p, g, wpb * 64u, lds, s);
-  if (S == 16 && getenv("RX_PROFILE_PACK"))  // stamped diagnostic build, see the kernel's PROF note
+  if (S == 16 && cfg.profile_pack)  // stamped diagnostic build, see the kernel's PROF note
     return launch_one(rx_sym_pack_kernel<16, false, true, false>, p, g, wpb * 64u, lds, s);
   return launch_one(rx_sym_pack_kernel<S, false, false, false>, p, g, wpb * 64u, lds, s);
 }
@@ -1534,6 +1540,7 @@ static int launch_pack(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s)
 // returns a hipError_t value (0 = hipSuccess)
 int rx_launch(const RxParams& p, const RxLaunchCfg& cfg, void* hip_stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+  g_verbose = cfg.verbose;
   switch (cfg.kernel) {
     case RX_KERNEL_CSR_WAVE:
       return cfg.stats ? launch_one(rx_csr_wave_kernel<true>, p, cfg.grid_blocks, cfg.block_threads, cfg.lds_bytes, s)

@@ -16,6 +16,9 @@ MODE_FULL, MODE_TB_COMPAT = 0, 1
 KERNEL_AUTO, KERNEL_CSR_WAVE, KERNEL_SYM_WAVE, KERNEL_SYM_GROUP, KERNEL_SYM_PACK, KERNEL_DFA = 0, 1, 2, 3, 4, 5
 KERNEL_NAMES = {0: "auto", 1: "csr_wave", 2: "sym_wave", 3: "sym_group", 4: "sym_pack", 5: "dfa"}
 
+# rx_opts.flags (A/B and diagnostic switches; read at plan creation, never from the environment)
+OPT_NO_PRUNE, OPT_FORCE_PRUNE, OPT_VERBOSE, OPT_PROFILE_PACK, OPT_NO_FOLD, OPT_FORCE_FOLD = 1, 2, 4, 8, 16, 32
+
 EVENT_DT = np.dtype([("stream", "<u4"), ("k", "<u4"), ("state", "<u4")])
 
 
@@ -31,7 +34,7 @@ class RxError(RuntimeError):
 class _Opts(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("mode", C.c_uint32), ("kernel", C.c_uint32),
                 ("stream", C.c_void_p), ("k_base", C.c_uint64), ("collect_stats", C.c_uint32),
-                ("group_lanes", C.c_uint32)]
+                ("group_lanes", C.c_uint32), ("flags", C.c_uint32)]
 
 
 class _Stats(C.Structure):
@@ -243,9 +246,10 @@ def n_passes(stream_len, mode):
     return stream_len + 1
 
 
-def _mk_opts(device, mode, kernel, stream, k_base, collect_stats, group_lanes=0):
+def _mk_opts(device, mode, kernel, stream, k_base, collect_stats, group_lanes=0, flags=0):
     o = _Opts()
     o.group_lanes = group_lanes
+    o.flags = flags
     o.struct_size = C.sizeof(_Opts)
     o.device, o.mode, o.kernel = device, mode, kernel
     o.stream = stream
@@ -308,12 +312,12 @@ def _as_rows(data):
 
 def match(nfa, data, mode=MODE_FULL, kernel=KERNEL_AUTO, device=-1, init_active=None, events_cap=1 << 20,
           want_match_count=False, want_total=True, want_anymatch=True, want_final=True, collect_stats=False,
-          k_base=0, group_lanes=0):
+          k_base=0, group_lanes=0, flags=0):
     """rx_match(): one-shot match of uint8 [n_streams, stream_len] host rows on one GPU."""
     data, stride = _as_rows(data)
     ns, sl = data.shape
     out = _Out(nfa, ns, sl, mode, events_cap, want_match_count, want_total, want_anymatch, want_final)
-    o = _mk_opts(device, mode, kernel, None, k_base, collect_stats, group_lanes)
+    o = _mk_opts(device, mode, kernel, None, k_base, collect_stats, group_lanes, flags)
     ia = None
     if init_active is not None:
         ia = np.ascontiguousarray(init_active, dtype=np.uint64)
@@ -325,12 +329,13 @@ def match(nfa, data, mode=MODE_FULL, kernel=KERNEL_AUTO, device=-1, init_active=
 
 
 def match_sharded(nfa, data, devices, mode=MODE_FULL, kernel=KERNEL_AUTO, events_cap=1 << 20,
-                  want_match_count=False, want_total=True, want_anymatch=True, want_final=True, collect_stats=False):
+                  want_match_count=False, want_total=True, want_anymatch=True, want_final=True, collect_stats=False,
+                  group_lanes=0, flags=0):
     """rx_match_sharded(): contiguous stream blocks over several GPUs of this process, no collective."""
     data, stride = _as_rows(data)
     ns, sl = data.shape
     out = _Out(nfa, ns, sl, mode, events_cap, want_match_count, want_total, want_anymatch, want_final)
-    o = _mk_opts(-1, mode, kernel, None, 0, collect_stats)
+    o = _mk_opts(-1, mode, kernel, None, 0, collect_stats, group_lanes, flags)
     devs = (C.c_int * len(devices))(*devices)
     _chk(lib().rx_match_sharded(nfa._h, data.ctypes.data, ns, sl, stride, devs, len(devices), C.byref(o),
                                 C.byref(out.r)), "rx_match_sharded")
@@ -342,11 +347,11 @@ class Plan:
 
     def __init__(self, nfa, max_streams, max_stream_len, mode=MODE_FULL, kernel=KERNEL_AUTO, device=-1, stream=None,
                  events_cap=1 << 20, want_match_count=False, want_anymatch=True, want_final=True, collect_stats=False,
-                 k_base=0, group_lanes=0):
+                 k_base=0, group_lanes=0, flags=0):
         self.nfa, self.mode = nfa, mode
         self.events_cap = events_cap
         self.want = (want_match_count, want_anymatch, want_final)
-        self._o = _mk_opts(device, mode, kernel, stream, k_base, collect_stats, group_lanes)
+        self._o = _mk_opts(device, mode, kernel, stream, k_base, collect_stats, group_lanes, flags)
         self._h = C.c_void_p()
         _chk(lib().rx_plan_create(nfa._h, C.byref(self._o), max_streams, max_stream_len, events_cap,
                                   int(want_match_count), int(want_anymatch), int(want_final), C.byref(self._h)),

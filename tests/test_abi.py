@@ -22,7 +22,7 @@ def test_header_symbols_exported(rx):
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/rxmatch.h but not exported"
     assert sorted(rx.host.ABI_SYMBOLS) == names  # the Python binding covers every entry point
-    assert L.rx_abi_version() == 1
+    assert L.rx_abi_version() == 2
 
 
 def test_header_is_plain_c(tmp_path):
@@ -39,13 +39,14 @@ def test_struct_layouts_match_binding(rx, tmp_path):
     import subprocess
     c = tmp_path / "s.c"
     c.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "rxmatch.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n",'
-                 'sizeof(rx_opts),sizeof(rx_result),sizeof(rx_stats),sizeof(rx_nfa_info),offsetof(rx_result,stats),offsetof(rx_opts,k_base));return 0;}\n')
+                 'sizeof(rx_opts),sizeof(rx_result),sizeof(rx_stats),sizeof(rx_nfa_info),offsetof(rx_result,stats),offsetof(rx_opts,k_base));'
+                 'printf("%zu\\n", offsetof(rx_opts,flags));return 0;}\n')
     exe = tmp_path / "s"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     h = rx.host
     assert got == [C.sizeof(h._Opts), C.sizeof(h._Result), C.sizeof(h._Stats), C.sizeof(h._Info),
-                   h._Result.stats.offset, h._Opts.k_base.offset]
+                   h._Result.stats.offset, h._Opts.k_base.offset, h._Opts.flags.offset]
 
 
 def test_error_strings(rx):
@@ -80,3 +81,36 @@ def test_no_device_fails_loudly(rx):
     with pytest.raises(rx.RxError) as e:
         rx.Plan(nfa, 1, 4)
     assert e.value.code == -6
+
+
+def test_pass_index_range_is_checked_before_any_device_work(rx):
+    """rx_event.k is 32 bits: k_base + passes of the batch beyond 2^32 is RX_EINVAL (-1), never a silent wrap —
+    checked before the device is touched, so it shows here without a GPU."""
+    import numpy as np
+    nfa = rx.Nfa.from_words(np.array([0, 1, 1, 0x61000001], np.uint32))
+    rows = np.zeros((1, 16), np.uint8)
+    for k_base in (2**32 - 16, 2**32, 2**40):
+        with pytest.raises(rx.RxError) as e:
+            rx.match(nfa, rows, k_base=k_base)
+        assert e.value.code == -1, k_base
+        with pytest.raises(rx.RxError) as e:
+            rx.Plan(nfa, 1, 16, k_base=k_base)
+        assert e.value.code == -1, k_base
+    try:  # the largest base that still fits: passes 0..16 -> k up to 2^32 - 1
+        rx.match(nfa, rows, k_base=2**32 - 17)
+    except rx.RxError as e:
+        assert e.code == -6  # no device here; on a GPU box it runs
+
+
+def test_options_struct_of_an_older_caller(rx):
+    """A caller built against ABI 1 passes an rx_opts that ends before `flags` (struct_size = 40): the library must
+    not read past it."""
+    import numpy as np
+    h = rx.host
+    nfa = rx.Nfa.from_words(np.array([0, 1, 1, 0x61000001], np.uint32))
+    o = h._Opts()
+    o.struct_size = h._Opts.flags.offset
+    o.device, o.mode, o.kernel = -1, 5, 0        # invalid mode: the options WERE read
+    o.flags = 0xFFFFFFFF                         # garbage behind the caller's struct
+    p = C.c_void_p()
+    assert h.lib().rx_plan_create(nfa._h, C.byref(o), 1, 4, 0, 0, 0, 0, C.byref(p)) == -1

@@ -99,6 +99,30 @@ def test_errors(rx):
         rx.Nfa.compile([b"a{1000}{1000}"])                        # expansion budget
 
 
+def test_hostile_patterns_return_errors_instead_of_crashing(rx, orx):
+    """Nothing throws or overflows the stack across the C boundary: deeply nested groups and quantifier towers are
+    refused with RX_EFORMAT, and very long literals / alternations — sequences are built as balanced trees — compile."""
+    for bad in (b"(" * 20000 + b"a" + b")" * 20000, b"(?:" * 5000 + b"a" + b")" * 5000,
+                b"(?:(?:a{0,1000}b){0,1000}c){0,1000}", b"a" + b"?" * 3 + b"{1000}" * 3):
+        with pytest.raises(rx.RxError) as e:
+            rx.Nfa.compile([bad])
+        assert e.value.code == -3, bad[:20]
+    lit = bytes(np.random.default_rng(1).integers(97, 123, size=80000, dtype=np.uint8))   # one 80 000-byte literal
+    nfa = rx.Nfa.compile([lit])
+    assert nfa.size == 80000 + 2 and nfa.n_accept == 1
+    alts = b"|".join(b"w%05d" % i for i in range(20000))                                 # 20 000 alternatives
+    nfa = rx.Nfa.compile([alts])
+    assert nfa.n_accept == 20000
+    # the balanced tree is the same language as the left-deep one: spot-check against the oracle + Python
+    pat = b"ab(c|d|e|f|g)h{2,4}i"
+    W = rx.Nfa.compile([pat]).words
+    size = orx.infer_size(W)
+    data = np.frombuffer(b"xxabchhixabghhhhhi.abdhi", np.uint8)
+    ends = sorted({m.end() for i in range(len(data)) for m in [re.compile(pat).match(data.tobytes(), i)] if m})
+    got = orx.match_batch(W, size, data)
+    assert sorted({int(e["k"]) for e in got["events"]}) == ends
+
+
 def make_ruleset(n, seed=20261004):
     """Synthetic stand-in for a Snort-like ruleset (BASELINE configs[4]): the reference ships no rules and
     none can be fetched, so patterns are seeded random content strings with classes, gaps and case folding."""

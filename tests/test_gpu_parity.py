@@ -272,10 +272,10 @@ def test_automata_in_the_reference_convention(rx, orx, kernels):
             check_equal(rx, orx, got, ref, ("convention", trial, kern, "plain"), stats=False)
 
 
-def test_lookahead_pruning_of_multi_target_rows(rx, orx, automata, traces, gpu_nfas, monkeypatch):
+def test_lookahead_pruning_of_multi_target_rows(rx, orx, automata, traces, gpu_nfas):
     """Pack kernel without statistics = the build that really runs: rows with several targets on one byte insert only
     the targets that survive the stream's next byte (never at the stream's last byte).  Events, counts, bitmaps and
-    final sets must not depend on it (RX_NO_PRUNE=1 = the unpruned build), for stream lengths around the 64-byte
+    final sets must not depend on it (rx_opts.flags RX_OPT_NO_PRUNE = the unpruned build), for stream lengths around the 64-byte
     window edges and in both modes."""
     cases = []
     W, size = automata["l7"]                                          # a multi-target row in nearly every pass
@@ -292,17 +292,16 @@ def test_lookahead_pruning_of_multi_target_rows(rx, orx, automata, traces, gpu_n
                             dense_rows=int(rng.integers(0, 3)))
         cases.append((("random", trial), rx.Nfa.from_words(Wr, sz), Wr, sz,
                       rng.integers(0, alpha, size=(int(rng.integers(1, 50)), int(rng.integers(0, 200))), dtype=np.uint8)))
-    monkeypatch.setenv("RX_FORCE_PRUNE", "1")  # these batches are too small for the probe that normally decides
+    force = rx.host.OPT_FORCE_PRUNE  # these batches are too small for the probe that normally decides
     for n, (name, nfa, Wc, sz, rows) in enumerate(cases):
         mode = n & 1
         ref = orx.match_batch(Wc, sz, rows, mode=mode, want_match_count=True, events_cap=1 << 22)
         for lanes in (4, 8, 13, 16, 32):
             kern = dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=lanes)
-            got = rx.match(nfa, rows, mode=mode, **kern, want_match_count=True, events_cap=1 << 22)
+            got = rx.match(nfa, rows, mode=mode, **kern, want_match_count=True, events_cap=1 << 22, flags=force)
             check_equal(rx, orx, got, ref, ("pruned", name, lanes), stats=False)
-        monkeypatch.setenv("RX_NO_PRUNE", "1")
-        got = rx.match(nfa, rows, mode=mode, kernel=rx.KERNEL_SYM_PACK, group_lanes=16, want_match_count=True, events_cap=1 << 22)
-        monkeypatch.delenv("RX_NO_PRUNE")
+        got = rx.match(nfa, rows, mode=mode, kernel=rx.KERNEL_SYM_PACK, group_lanes=16, want_match_count=True, events_cap=1 << 22,
+                       flags=rx.host.OPT_NO_PRUNE)
         check_equal(rx, orx, got, ref, ("unpruned", name), stats=False)
 
 
@@ -459,16 +458,20 @@ def test_full_size_ruleset_standin(rx, orx):
 
 
 def test_automaton_too_large_for_lds_fails_loudly(rx):
-    """The wave kernels keep two size-bit bitmasks per stream in LDS (160 KB per CU): beyond ~650 000 states every
-    compute call must fail with RX_ECAPACITY (-8) instead of computing something else."""
-    size = 700_000
-    e = [(0, c, 1) for c in range(256)] + [(1, c, 1) for c in range(256)] + [(1, 97, 699_998), (699_998, 98, 699_999)]
-    nfa = rx.Nfa.from_words(build_words(size, e), size)
-    rows = np.frombuffer(b"xxabxx", np.uint8)
-    for kern in (dict(kernel=rx.KERNEL_AUTO), dict(kernel=rx.KERNEL_SYM_PACK), dict(kernel=rx.KERNEL_CSR_WAVE)):
-        with pytest.raises(rx.RxError) as err:
-            rx.match(nfa, rows, **kern)
-        assert err.value.code == -8, kern
+    """The wave kernels keep two size-bit bitmasks per stream in LDS (160 KB per CU): beyond 650 000 states the
+    automaton is refused with RX_ECAPACITY (-8) when it is loaded — before any index is built — and just below
+    that limit every kernel still runs."""
+    e = [(0, c, 1) for c in range(256)] + [(1, c, 1) for c in range(256)]
+    with pytest.raises(rx.RxError) as err:
+        rx.Nfa.from_words(build_words(700_000, e + [(1, 97, 699_998), (699_998, 98, 699_999)]), 700_000)
+    assert err.value.code == -8
+    size = 640_000
+    nfa = rx.Nfa.from_words(build_words(size, e + [(1, 97, size - 2), (size - 2, 98, size - 1)]), size)
+    rows = np.frombuffer(b"xxabxxab", np.uint8)
+    for kern in (dict(kernel=rx.KERNEL_AUTO), dict(kernel=rx.KERNEL_SYM_PACK), dict(kernel=rx.KERNEL_CSR_WAVE),
+                 dict(kernel=rx.KERNEL_SYM_WAVE)):
+        got = rx.match(nfa, rows, **kern)
+        assert [(int(v["k"]), int(v["state"])) for v in got["events"]] == [(4, size - 1), (8, size - 1)], kern
 
 
 def test_sharded_entry_point_single_device(rx, orx, automata, traces, gpu_nfas):

@@ -77,11 +77,9 @@ def one_case(rng, trial):
     ks = [KERNELS[i] for i in rng.choice(len(KERNELS), size=5, replace=False)] + [KERNELS[-1]]
     for kern in ks:
         stats = bool(rng.integers(2))  # the statistics build and the plain build are different kernels (pruning, marks)
-        if rng.integers(2):
-            os.environ["RX_FORCE_PRUNE"] = "1"   # batches here are too small for the probe that normally decides
-        else:
-            os.environ.pop("RX_FORCE_PRUNE", None)
-        got = rx.match(nfa, rows, mode=mode, want_match_count=True, collect_stats=stats, events_cap=CAP, **kern)
+        # batches here are too small for the probe that normally decides: force the pruned / folded builds half the time
+        flags = (rx.host.OPT_FORCE_PRUNE if rng.integers(2) else 0) | (rx.host.OPT_FORCE_FOLD if rng.integers(2) else 0)
+        got = rx.match(nfa, rows, mode=mode, want_match_count=True, collect_stats=stats, events_cap=CAP, flags=flags, **kern)
         ok = (got["n_events"] == ref["n_events"] and (overflow or np.array_equal(got["events"], ref["events"].astype(got["events"].dtype)))
               and np.array_equal(got["match_count"], ref["match_count"]) and np.array_equal(got["final_active"], ref["final_active"])
               and np.array_equal(got["anymatch"][:, :ref["anymatch"].shape[1]], ref["anymatch"])
