@@ -2,36 +2,48 @@
 """bench.py — BASELINE.json's metric: input Gbit/s matched against the snort_16 NFA at N MI355X.
 
 A "step" is one pass of the hot path over one resident batch: ONE launch of the match kernel over
-`streams-per-gpu` streams x `stream-len` bytes that already sit in HBM.  Default workload at N=1 is
-BASELINE.json configs[2]: snort_16 CSR NFA, 65 536 concurrent 1 KB streams, distribution T (windows of
-the reference's own snort_16 traces).  With N>1 (one process per GPU, launched by
-torch.distributed.run) every rank owns its own contiguous block of 65 536 streams of the same
-generator — weak scaling, no data-path collective; the only traffic is the barrier and the scalar
-all-reduces of the report.
+`streams-per-gpu` streams x `stream-len` bytes that already sit in HBM.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py                          # N=1: BASELINE configs[2], 65 536 x 1 KB, distribution T
+    python bench.py --gpus 8                 # spawns 8 ranks itself: configs[3], 131 072 x 1 KB per GPU
+    python bench.py --gpus 8 --config 4      # configs[4] stand-in: snort_16 on 4 KB T windows, 131 072 per GPU
+    python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8   # what the driver does: same result
 
-Prints ONE JSON line (rank 0).  `roofline.achieved` = ALGORITHMIC bytes per launch (SURVEY.md §8d:
-per consumed byte 1 + sum_{i in S_k}(8 + 4 deg(i)), + 1 bit per pass + 12 B per accept event; counted
-on the GPU by the collect_stats build of the same kernel and cross-checked against the CPU oracle on
-a sample) divided by the mean hipEvent duration of the kernel inside the timed region.  The table is
-cache-resident and the shipped kernel reads a per-(state,byte) slice index instead of whole rows, so
-this is an EFFECTIVE bandwidth and may exceed the HBM peak; `roofline.traffic` carries the measured
-HBM bytes per launch (rocprofv3 PMC, profiles/) when available.
+With N>1 every rank (one process per GPU) owns its own contiguous block of streams of the same generator —
+weak scaling, no data-path collective; the only traffic is the barrier and the scalar all-reduces of the report.
+Invoked directly with --gpus N>1 (no WORLD_SIZE in the environment) this script starts the N ranks itself as
+children (`python -m torch.distributed.run`) BEFORE it touches torch.cuda / HIP and relays rank 0's line.
+
+Prints ONE JSON line (rank 0).  `roofline`: `frac` = compulsory HBM bytes of one launch (input + outputs + table
+once) / mean hipEvent duration of the kernel in the timed region / 8 TB/s — the kernel is nowhere near HBM-bound
+(the table is cache-resident), which is what the figure says; what bounds it is in `roofline.limiter` and, when the
+tracked rocprofv3 summary under profiles/ was taken from this very kernel source, `roofline.pmc`.  SURVEY.md §8(d)'s
+FPGA-style algorithmic byte count (whole rows re-read per active state) is reported separately as
+`roofline.effective_vs_fpga_row_bytes`; `north_star_form` times the wavefront-per-stream kernel that really reads
+those rows from the unchanged CSR.
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+# BASELINE.json configs by index: (streams per GPU, stream length, workload, description)
+CONFIGS = {
+    2: (65536, 1024, "T", "BASELINE configs[2]"),
+    3: (131072, 1024, "T", "BASELINE configs[3] (1 Mi streams over 8 GPUs = 131 072 per GPU)"),
+    4: (131072, 4096, "T", "BASELINE configs[4] stand-in (SURVEY 8d-5: the shipped snort_16 table itself, 9 514 ~ 10k states, "
+                           "on 4 096-byte T windows; no rule files exist offline)"),
+}
 
 
 def parse():
@@ -39,21 +51,61 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--streams-per-gpu", type=int, default=65536)
-    ap.add_argument("--stream-len", type=int, default=1024)
-    ap.add_argument("--workload", choices=["T", "U", "R", "L"], default="T",
-                    help="T trace windows (headline), U uniform bytes, R synthetic ~10k-state ruleset stand-in, "
-                         "L the other shipped automaton (l7-filter) on windows of its own traces")
+    ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=None,
+                    help="BASELINE.json configs index; default 2 at --gpus 1, 3 at --gpus N>1")
+    ap.add_argument("--streams-per-gpu", type=int, default=None)
+    ap.add_argument("--stream-len", type=int, default=None)
+    ap.add_argument("--workload", choices=["T", "U", "R", "L"], default=None,
+                    help="T trace windows (headline), U uniform bytes, R synthetic ~10k-state ruleset (second stand-in for "
+                         "configs[4]), L the other shipped automaton (l7-filter) on windows of its own traces")
     ap.add_argument("--kernel", default="auto", choices=["auto", "csr_wave", "sym_wave", "sym_group", "sym_pack", "dfa"])
     ap.add_argument("--group-lanes", type=int, default=0)
+    ap.add_argument("--flags", type=int, default=0, help="rx_opts.flags (RX_OPT_* bits: A/B and diagnostic switches)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="cap on oracle threads (box share: 16 per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--all-kernels", action="store_true", help="also time the other kernels (extra keys)")
-    ap.add_argument("--no-second-distribution", action="store_true", help="skip the extra distribution-U measurement")
+    ap.add_argument("--no-second-distribution", action="store_true",
+                    help="skip the extra measurements (distribution U, single stream, north-star form, host-to-host)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) for real multi-GPU runs; gloo only to rehearse ranks on fewer GPUs")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
-    return ap.parse_args()
+    a = ap.parse_args()
+    cfg = a.config if a.config is not None else (2 if a.gpus == 1 else 3)
+    ns, sl, wl, desc = CONFIGS[cfg]
+    a.config = cfg
+    a.config_desc = desc if (a.streams_per_gpu is None and a.stream_len is None and a.workload is None) else \
+        f"custom shape (preset {cfg} overridden)"
+    a.streams_per_gpu = a.streams_per_gpu or ns
+    a.stream_len = a.stream_len or sl
+    a.workload = a.workload or wl
+    return a
+
+
+def spawn_ranks(a):
+    """--gpus N>1 invoked directly: start the N ranks as CHILDREN before this process touches the GPU (a process that
+    has initialised HIP must never exec), relay rank 0's JSON line, exit with the launcher's code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1])
+    else:
+        sys.stdout.write(proc.stdout)
+    sys.exit(proc.returncode)
+
+
+def kernel_source_sha16():
+    h = hashlib.sha256()
+    for f in ("rx_kernels.hip", "rx_internal.hpp"):
+        h.update(open(os.path.join(ROOT, "regex-fpga_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def make_rows(rx, workload, first, count, stream_len, traces):
@@ -74,18 +126,19 @@ def time_kernel(plan, steps):
 
 def main():
     a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)  # does not return
+    import numpy as np
     import torch  # first: librxmatch must bind to the HIP runtime torch already loaded
     import torch.distributed as dist
     rx = importlib.import_module("regex-fpga_amd")
     rx.host.lib()  # fails loudly if the HIP extension is missing — there is no fallback
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if a.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
     if a.same_device:
         local = 0
     torch.cuda.set_device(local)
@@ -101,7 +154,7 @@ def main():
     wl = rx.workloads
     kern = {"auto": rx.KERNEL_AUTO, "csr_wave": rx.KERNEL_CSR_WAVE, "sym_wave": rx.KERNEL_SYM_WAVE,
             "sym_group": rx.KERNEL_SYM_GROUP, "sym_pack": rx.KERNEL_SYM_PACK, "dfa": rx.KERNEL_DFA}[a.kernel]
-    if a.workload == "R":  # BASELINE configs[4] stand-in: synthetic ruleset compiled by rx_compile_patterns
+    if a.workload == "R":  # second stand-in for configs[4]: synthetic ruleset compiled by rx_compile_patterns
         traces = wl.synthetic_ruleset()
         nfa = rx.Nfa.compile(traces)
     elif a.workload == "L":
@@ -113,6 +166,7 @@ def main():
     ns, sl = a.streams_per_gpu, a.stream_len
     first = rank * ns  # contiguous block per rank (sharding.shard_range of world*ns streams)
     rows = make_rows(rx, a.workload, first, ns, sl, traces)
+    ev_cap = 1 << 22 if sl <= 1024 else 1 << 24
 
     # inputs resident in HBM before the timed region (torch owns the buffer; plumbing only)
     torch.zeros(1, device=dev)  # context + allocator warm, so that the copy below times the copy
@@ -128,20 +182,18 @@ def main():
     h2d_pinned_s = time.perf_counter() - t_h2d0
     del h_pin
     stream = torch.cuda.current_stream().cuda_stream
-    plan = rx.Plan(nfa, ns, sl, mode=rx.MODE_FULL, kernel=kern, device=local, stream=stream, events_cap=1 << 22,
-                   want_match_count=False, want_anymatch=True, want_final=True, group_lanes=a.group_lanes)
+    common = dict(mode=rx.MODE_FULL, kernel=kern, device=local, stream=stream, events_cap=ev_cap,
+                  group_lanes=a.group_lanes, flags=a.flags)
+    plan = rx.Plan(nfa, ns, sl, want_match_count=False, want_anymatch=True, want_final=True, **common)
     plan.set_device_input(d_rows.data_ptr(), ns, sl, sl, keepalive=d_rows)
 
     # algorithmic bytes of one launch: collect_stats build of the same kernel, untimed
-    splan = rx.Plan(nfa, ns, sl, mode=rx.MODE_FULL, kernel=kern, device=local, stream=stream, events_cap=1 << 22,
-                    want_match_count=False, want_anymatch=True, want_final=True, collect_stats=True,
-                    group_lanes=a.group_lanes)
+    splan = rx.Plan(nfa, ns, sl, want_match_count=False, want_anymatch=True, want_final=True, collect_stats=True, **common)
     splan.set_device_input(d_rows.data_ptr(), ns, sl, sl, keepalive=d_rows)
     splan.launch()
     sres = splan.download()
     alg_bytes = sres["stats"]["alg_bytes"]
     n_events = sres["stats"]["n_events"]
-    kernel_used = rx.host.KERNEL_NAMES[sres["stats"]["kernel_used"]]
     splan.close()
 
     for _ in range(a.warmup):
@@ -160,6 +212,8 @@ def main():
     nk, ksum, kmin, kmax = plan.kernel_times()
     res = plan.download()
     assert res["stats"]["n_events"] == n_events, "timed kernel and stats kernel disagree"
+    kernel_used = rx.host.KERNEL_NAMES[res["stats"]["kernel_used"]]
+    variant = res["stats"].get("variant", "")
     sec, ev_total, bytes_total = rx.sharding.reduce_report(dist if world > 1 else None, rdev, t1 - t0, n_events,
                                                            ns * sl)
     kavg_ms = ksum / max(nk, 1)
@@ -170,74 +224,107 @@ def main():
         return
 
     gbit = 8.0 * bytes_total * a.steps / sec / 1e9
+    npass = sl + 1
+    compulsory = int(ns * sl + ns * ((npass + 31) // 32) * 4 + ns * nfa.nw64 * 8 + n_events * 12 + nfa.n_words * 4)
+    hbm_gbs = compulsory / (kavg_ms * 1e-3) / 1e9
+    eff_gbs = alg_bytes / (kavg_ms * 1e-3) / 1e9
 
-    # host buffers in, host results out, through the library's own copies (pageable memory, resident plan): what a
-    # caller of the C-ABI that does not keep its streams in HBM gets.  Reported beside `value`, never as `value`.
-    hplan = rx.Plan(nfa, ns, sl, mode=rx.MODE_FULL, kernel=kern, device=local, stream=stream, events_cap=1 << 22,
-                    want_match_count=False, want_anymatch=True, want_final=True, group_lanes=a.group_lanes)
-    hplan.upload(rows)
-    hplan.launch()
-    hplan.download()  # warm: buffers allocated, AUTO decided
-    t_h = time.perf_counter()
-    hplan.upload(rows)
-    hplan.launch()
-    hres = hplan.download()
-    host_to_host_s = time.perf_counter() - t_h
-    assert hres["stats"]["n_events"] == n_events
-    hplan.close()
-    achieved = alg_bytes / (kavg_ms * 1e-3) / 1e9
-    traffic = None
+    # HBM bytes per launch measured with rocprofv3 PMC passes (profiles/, tools/summarize_profile.py): valid only for
+    # exactly this kernel source, kernel variant and shape — anything else is reported as null, loudly
+    traffic, pmc, traffic_note = None, None, "no tracked rocprofv3 PMC summary for this kernel variant and shape"
+    tkey = f"{kernel_used}{(':' + variant) if variant else ''}:{a.workload}:{ns}x{sl}"
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            tj = json.load(open(tpath))
-            traffic = tj.get(f"{kernel_used}:{a.workload}:{ns}x{sl}", {}).get("hbm_bytes_per_launch")
+            ent = json.load(open(tpath)).get(tkey)
         except Exception:
-            traffic = None
+            ent = None
+        if ent is not None:
+            if ent.get("src_sha16") == kernel_source_sha16():
+                traffic, pmc = ent.get("hbm_bytes_per_launch"), ent.get("pmc")
+                traffic_note = ent.get("source", "")
+            else:
+                traffic_note = (f"profiles/traffic.json[{tkey}] was measured on another version of the kernel source "
+                                f"({ent.get('src_sha16')}): STALE, not reported")
+    shape_desc = f"{ns} x {sl} B streams per GPU"
+    dist_desc = {"T": "windows of the reference snort_16 traces", "U": "splitmix64 uniform bytes"}.get(a.workload, "")
+    if a.workload in ("T", "U"):
+        workload = (f"snort_16 CSR NFA (9514 states, 79856 edges), {shape_desc}, distribution {a.workload} ({dist_desc}), "
+                    f"full mode from reset, {a.config_desc}")
+    elif a.workload == "L":
+        workload = (f"l7-filter CSR NFA (the reference's other shipped table: {nfa.size} states, {nfa.nnz} edges), {shape_desc}: "
+                    f"windows of its own lo/hi traces, full mode from reset")
+    else:
+        workload = (f"SECOND STAND-IN for configs[4]: synthetic 700-pattern ruleset compiled to one CSR NFA ({nfa.size} states, "
+                    f"{nfa.nnz} edges), {shape_desc} of pseudo-traffic")
     out = {
         "metric": "input Gbit/s matched vs snort_16 NFA" if a.workload in ("T", "U") else
-                  "input Gbit/s matched (NOT the headline automaton, see config.workload)", "value": round(gbit, 3), "unit": "Gbit/s",
+                  "input Gbit/s matched (NOT the headline automaton, see config.workload)",
+        "value": round(gbit, 3), "unit": "Gbit/s",
         "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(sec / a.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": (f"snort_16 CSR NFA (9514 states, 79856 edges), {ns} x {sl} B streams per GPU, "
-                                f"distribution {a.workload} ({'windows of the reference snort_16 traces' if a.workload == 'T' else 'splitmix64 uniform bytes'}), "
-                                f"full mode from reset, BASELINE configs[2]") if a.workload in ("T", "U") else
-                               (f"l7-filter CSR NFA (the reference's other shipped table: {nfa.size} states, {nfa.nnz} edges), "
-                                f"{ns} x {sl} B windows of its own lo/hi traces per GPU, full mode from reset") if a.workload == "L" else
-                               (f"STAND-IN for configs[4]: synthetic 700-pattern ruleset compiled to one CSR NFA "
-                                f"({nfa.size} states, {nfa.nnz} edges), {ns} x {sl} B pseudo-traffic streams per GPU"),
-                   "kernel": kernel_used, "streams_per_gpu": ns, "stream_len": sl,
-                   "parallelism": f"streams sharded over {a.gpus} GPU(s), no collective"},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "alg_bytes_per_launch": alg_bytes, "kernel_ms_avg": round(kavg_ms, 4),
-                     "kernel_ms_min": round(kmin, 4), "kernel_ms_max": round(kmax, 4),
-                     # also against the ~6.29 TB/s a streaming kernel reaches, and the compulsory HBM bytes
-                     # of one launch = input + outputs (bitmap, final sets, events) + the table read once
-                     "frac_of_achievable_6290": round(achieved / 6290.0, 4),
-                     "compulsory_hbm_bytes": int(ns * sl + ns * ((sl + 1 + 31) // 32) * 4 + ns * nfa.nw64 * 8
-                                                 + n_events * 12 + nfa.n_words * 4),
-                     "physical_hbm_GBs": round(traffic / (kavg_ms * 1e-3) / 1e9, 1) if traffic else None,
-                     "note": "effective bandwidth: algorithmic (FPGA-style whole-row) bytes / kernel time; "
-                             "the 357 KB table is cache-resident, compulsory HBM traffic is ~1 B per input byte"},
+        "config": {"workload": workload, "baseline_config_index": a.config, "kernel": kernel_used, "kernel_variant": variant,
+                   "streams_per_gpu": ns, "stream_len": sl,
+                   "parallelism": f"streams sharded over {a.gpus} GPU(s), contiguous blocks, no collective"},
+        "roofline": {"bound": "hbm", "achieved": round(hbm_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(hbm_gbs / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_note": traffic_note,
+                     "compulsory_hbm_bytes_per_launch": compulsory,
+                     "kernel_ms_avg": round(kavg_ms, 4), "kernel_ms_min": round(kmin, 4), "kernel_ms_max": round(kmax, 4),
+                     "limiter": "issue + dependent latency per pass, not HBM: the table and its slice index are cache-resident, "
+                                "compulsory HBM traffic is ~2 B per input byte (input + final sets + bitmap)",
+                     "pmc": pmc,
+                     # SURVEY 8d's figure: what the FPGA design's row-by-row reads would have moved for the same work
+                     "effective_vs_fpga_row_bytes": {"alg_bytes_per_launch": alg_bytes, "GBs": round(eff_gbs, 2),
+                                                      "x_hbm_peak": round(eff_gbs / HBM_PEAK_GBS, 3),
+                                                      "note": "FPGA-style whole-row bytes (1 + sum(8 + 4 deg) per pass + outputs) / "
+                                                              "kernel time; this kernel reads one slice-index dword per active "
+                                                              "state instead, so this is work done, not bytes moved"}},
         "accept_events_per_launch": ev_total,
         "h2d_inclusive_gbit_s": round(8.0 * ns * sl / (h2d_s + kavg_ms * 1e-3) / 1e9, 3),
-        "host_to_host_gbit_s": round(8.0 * ns * sl / host_to_host_s / 1e9, 3),
         "h2d_pinned_inclusive_gbit_s": round(8.0 * ns * sl / (h2d_pinned_s + kavg_ms * 1e-3) / 1e9, 3),
     }
 
-    if a.workload == "T" and not a.no_second_distribution:
+    if world == 1 and not a.no_second_distribution:
+        # host buffers in, host results out, through the library's own copies (pageable memory, resident plan): what a
+        # caller of the C-ABI that does not keep its streams in HBM gets.  Reported beside `value`, never as `value`.
+        hplan = rx.Plan(nfa, ns, sl, want_match_count=False, want_anymatch=True, want_final=True, **common)
+        hplan.upload(rows)
+        hplan.launch()
+        hplan.download()  # warm: buffers allocated, AUTO decided
+        t_h = time.perf_counter()
+        hplan.upload(rows)
+        hplan.launch()
+        hres = hplan.download()
+        host_to_host_s = time.perf_counter() - t_h
+        assert hres["stats"]["n_events"] == n_events
+        hplan.close()
+        out["host_to_host_gbit_s"] = round(8.0 * ns * sl / host_to_host_s / 1e9, 3)
+
+        # north-star form: ONE WAVEFRONT OWNS ONE STREAM and reads row_ptr pairs + whole rows from the unchanged CSR
+        # (Design/FPGA.v:166-207, :227-714): here the algorithmic bytes ARE the bytes the kernel loads (from L1/L2)
+        cp = rx.Plan(nfa, ns, sl, mode=rx.MODE_FULL, kernel=rx.KERNEL_CSR_WAVE, device=local, stream=stream, events_cap=ev_cap)
+        cp.set_device_input(d_rows.data_ptr(), ns, sl, sl, keepalive=d_rows)
+        time_kernel(cp, 1)
+        cavg, cmin, cmax = time_kernel(cp, 3)
+        cres = cp.download()
+        assert cres["stats"]["n_events"] == n_events
+        cp.close()
+        out["north_star_form"] = {"kernel": "csr_wave (one wavefront per stream, unchanged CSR rows)",
+                                  "kernel_ms_avg": round(cavg, 3), "gbit_s": round(8.0 * ns * sl / (cavg * 1e-3) / 1e9, 3),
+                                  "csr_read_GBs": round(alg_bytes / (cavg * 1e-3) / 1e9, 1),
+                                  "note": "row_ptr pairs + whole rows of every active state per pass, served by L1/L2 (table 357 KB); "
+                                          "rocprofv3 summary: profiles/r02_csr_wave/"}
+
+    if a.workload == "T" and world == 1 and not a.no_second_distribution:
         # SURVEY.md §8d asks for both seeded distributions; T above is the headline, U is reported beside it
         urows = make_rows(rx, "U", first, ns, sl, traces)
         d_u = torch.from_numpy(urows).to(dev)
-        up = rx.Plan(nfa, ns, sl, mode=rx.MODE_FULL, kernel=kern, device=local, stream=stream, events_cap=1 << 22,
-                     collect_stats=True, group_lanes=a.group_lanes)
+        up = rx.Plan(nfa, ns, sl, collect_stats=True, **common)
         up.set_device_input(d_u.data_ptr(), ns, sl, sl, keepalive=d_u)
         up.launch()
         ualg = up.download()["stats"]["alg_bytes"]
         up.close()
-        up = rx.Plan(nfa, ns, sl, mode=rx.MODE_FULL, kernel=kern, device=local, stream=stream, events_cap=1 << 22,
-                     group_lanes=a.group_lanes)
+        up = rx.Plan(nfa, ns, sl, **common)
         up.set_device_input(d_u.data_ptr(), ns, sl, sl, keepalive=d_u)
         time_kernel(up, 2)
         uavg, umin, umax = time_kernel(up, max(a.steps // 2, 3))
@@ -245,23 +332,26 @@ def main():
         out["distribution_U"] = {"gbit_s": round(8.0 * ns * sl / (uavg * 1e-3) / 1e9, 3), "kernel_ms_avg": round(uavg, 4),
                                  "alg_bytes_per_launch": ualg, "eff_GBs": round(ualg / (uavg * 1e-3) / 1e9, 2),
                                  "kernel": rx.host.KERNEL_NAMES[ures["stats"]["kernel_used"]],
+                                 "kernel_variant": ures["stats"].get("variant", ""),
                                  "accept_events_per_launch": ures["stats"]["n_events"]}
         up.close()
         del d_u
-        # BASELINE configs[1]: ONE shipped trace as ONE stream, tb-compat (a correctness config: a single stream is a
-        # single dependency chain, so this is latency, not throughput; the parity tests check its match vector)
+        # BASELINE configs[1]: ONE shipped trace as ONE stream, tb-compat (a single stream is a single dependency chain,
+        # so this is a latency figure; the parity tests check its match vector)
         one = traces[1][:200000].reshape(1, -1)
         d_one = torch.from_numpy(one.copy()).to(dev)
         sp = rx.Plan(nfa, 1, one.shape[1], mode=rx.MODE_TB_COMPAT, kernel=kern, device=local, stream=stream,
-                     events_cap=1 << 20, group_lanes=a.group_lanes)
+                     events_cap=1 << 20, group_lanes=a.group_lanes, flags=a.flags)
         sp.set_device_input(d_one.data_ptr(), 1, one.shape[1], one.shape[1], keepalive=d_one)
         time_kernel(sp, 1)
         savg, _, _ = time_kernel(sp, 2)
         sres = sp.download()
         out["single_stream_config1"] = {"input": "input_trace_hi_snort_16.mem, 200 000 B, tb-compat", "kernel_ms": round(savg, 3),
                                         "mbit_s": round(8.0 * one.shape[1] / (savg * 1e-3) / 1e6, 2),
+                                        "ns_per_pass": round(savg * 1e6 / (one.shape[1] - 1), 1),
                                         "accept_events": sres["stats"]["n_events"],
-                                        "kernel": rx.host.KERNEL_NAMES[sres["stats"]["kernel_used"]]}
+                                        "kernel": rx.host.KERNEL_NAMES[sres["stats"]["kernel_used"]],
+                                        "kernel_variant": sres["stats"].get("variant", "")}
         sp.close()
         del d_one
 
@@ -270,17 +360,16 @@ def main():
         for name, kid, gl in (("csr_wave", rx.KERNEL_CSR_WAVE, 0), ("sym_wave", rx.KERNEL_SYM_WAVE, 0),
                               ("sym_group1", rx.KERNEL_SYM_GROUP, 1), ("sym_group2", rx.KERNEL_SYM_GROUP, 2),
                               ("sym_group4", rx.KERNEL_SYM_GROUP, 4), ("sym_group8", rx.KERNEL_SYM_GROUP, 8),
-                              ("sym_group16", rx.KERNEL_SYM_GROUP, 16), ("sym_pack2", rx.KERNEL_SYM_PACK, 2), ("sym_pack4", rx.KERNEL_SYM_PACK, 4), ("sym_pack8", rx.KERNEL_SYM_PACK, 8), ("sym_pack12", rx.KERNEL_SYM_PACK, 12),
-                              ("sym_pack16", rx.KERNEL_SYM_PACK, 16), ("sym_pack20", rx.KERNEL_SYM_PACK, 20),
-                              ("sym_pack24", rx.KERNEL_SYM_PACK, 24), ("sym_pack32", rx.KERNEL_SYM_PACK, 32),
-                              ("dfa_warm", rx.KERNEL_DFA, 0)):
-            p2 = rx.Plan(nfa, ns, sl, mode=rx.MODE_FULL, kernel=kid, device=local, stream=stream, events_cap=1 << 22,
-                         group_lanes=gl)
+                              ("sym_group16", rx.KERNEL_SYM_GROUP, 16), ("sym_pack4", rx.KERNEL_SYM_PACK, 4),
+                              ("sym_pack8", rx.KERNEL_SYM_PACK, 8), ("sym_pack13", rx.KERNEL_SYM_PACK, 13),
+                              ("sym_pack16", rx.KERNEL_SYM_PACK, 16), ("sym_pack24", rx.KERNEL_SYM_PACK, 24),
+                              ("sym_pack32", rx.KERNEL_SYM_PACK, 32), ("dfa_warm", rx.KERNEL_DFA, 0)):
+            p2 = rx.Plan(nfa, ns, sl, mode=rx.MODE_FULL, kernel=kid, device=local, stream=stream, events_cap=ev_cap,
+                         group_lanes=gl, flags=a.flags)
             p2.set_device_input(d_rows.data_ptr(), ns, sl, sl, keepalive=d_rows)
             time_kernel(p2, 2)
             avg, mn, mx = time_kernel(p2, max(a.steps // 2, 3))
-            extra[name] = {"kernel_ms_avg": round(avg, 4), "gbit_s": round(8.0 * ns * sl / (avg * 1e-3) / 1e9, 3),
-                           "eff_GBs": round(alg_bytes / (avg * 1e-3) / 1e9, 2)}
+            extra[name] = {"kernel_ms_avg": round(avg, 4), "gbit_s": round(8.0 * ns * sl / (avg * 1e-3) / 1e9, 3)}
             p2.close()
         out["kernels"] = extra
 
@@ -296,9 +385,9 @@ def main():
         nsamp = int(min(ns, max(nthr * 64, 15.0 / per_stream_s)))
         t = time.perf_counter()
         ref = orx.match_batch(W, size, rows[:nsamp], mode=orx.MODE_FULL, nthreads=nthr, want_final=False,
-                              events_cap=1 << 22)
+                              events_cap=ev_cap)
         cpu_s = time.perf_counter() - t
-        # cross-check the GPU's algorithmic-byte count and events on the sample
+        # cross-check the GPU's events on the sample
         gev = res["events"]
         gev = gev[gev["stream"] < nsamp]
         ok = bool(np.array_equal(gev, ref["events"].astype(gev.dtype)))

@@ -182,7 +182,15 @@ typedef struct rx_stats {
   uint64_t tb_cycles;    /* collect_stats == 2: what `$display("Total no. cycles: %d", cycles)`
                             (testbench_BLK_Mem.sv:84) prints for the pair(s), summed over pairs;
                             0 if unavailable                                               */
+  /* ABI >= 2 (written only when the caller's rx_result.struct_size covers them) */
+  uint32_t lanes_used;   /* SYM_GROUP: lanes per stream; SYM_PACK: streams per wavefront; else 0 */
+  uint32_t variant;      /* RX_VARIANT_* bits of the build that ran                              */
 } rx_stats;
+enum {
+  RX_VARIANT_STATS = 1u,  /* the statistics build (collect_stats)                          */
+  RX_VARIANT_PRUNE = 2u,  /* look-ahead pruning of multi-target rows                       */
+  RX_VARIANT_FOLD = 4u    /* the always-on `.*` state folded out of the lists              */
+};
 
 /* All output arrays are caller-allocated and optional (NULL = not wanted). */
 typedef struct rx_result {

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -841,9 +842,26 @@ static bool ev_less(const rx_event& a, const rx_event& b) {
   return a.state < b.state;
 }
 
-extern "C" int rx_plan_download(rx_plan* p, rx_result* res) {
+// rx_result as the caller's version of the header laid it out (see read_opts)
+static size_t result_bytes(const rx_result* res) {
+  return res->struct_size ? std::min<size_t>(res->struct_size, sizeof(rx_result)) : sizeof(rx_result);
+}
+
+static int plan_download(rx_plan* p, rx_result* res);
+
+extern "C" int rx_plan_download(rx_plan* p, rx_result* caller) {
   RX_TRY
-  if (!p || !res) return RX_EINVAL;
+  if (!p || !caller) return RX_EINVAL;
+  rx_result full{};  // work on a full-size copy: fields behind the caller's struct_size are never written to it
+  const size_t have = result_bytes(caller);
+  memcpy(&full, caller, have);
+  const int rc = plan_download(p, &full);
+  memcpy(caller, &full, have);
+  return rc;
+  RX_CATCH
+}
+
+static int plan_download(rx_plan* p, rx_result* res) {
   if (!p->launched) return RX_ESTATE;
   int dev;
   int rc = bind_device(p->device, &dev);
@@ -868,6 +886,9 @@ extern "C" int rx_plan_download(rx_plan* p, rx_result* res) {
   st.n_events = cnt[0];
   st.kernel_ms = p->last_ms;
   st.kernel_used = p->cfg.kernel;
+  st.lanes_used = (p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK) ? p->cfg.group_lanes : 0u;
+  st.variant = (p->cfg.stats ? RX_VARIANT_STATS : 0u) |
+               (p->cfg.kernel == RX_KERNEL_SYM_PACK && p->cfg.prune && !p->cfg.stats ? RX_VARIANT_PRUNE : 0u);
   st.n_launches = (p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK ||
                    p->cfg.kernel == RX_KERNEL_DFA) ? 2 : 1;
   if (p->cfg.stats) {
@@ -916,7 +937,6 @@ extern "C" int rx_plan_download(rx_plan* p, rx_result* res) {
                      hipMemcpyDeviceToHost));
   }
   return RX_OK;
-  RX_CATCH
 }
 
 // ---- one-shot -------------------------------------------------------------------------------------
@@ -944,7 +964,7 @@ extern "C" int rx_match(const rx_nfa* nfa, const uint8_t* bytes, size_t n_stream
   if ((rc = rx_plan_launch(p))) return done(rc);
   if ((rc = rx_plan_sync(p, nullptr))) return done(rc);
   const auto w0 = std::chrono::steady_clock::now();
-  if ((rc = rx_plan_download(p, res))) return done(rc);
+  if ((rc = rx_plan_download(p, res))) return done(rc);  // honours res->struct_size
   const auto w1 = std::chrono::steady_clock::now();
   float h2d = 0;
   (void)hipEventElapsedTime(&h2d, t0, t1);
@@ -1002,7 +1022,11 @@ extern "C" int rx_match_sharded(const rx_nfa* nfa, const uint8_t* bytes, size_t 
     });
   }
   for (auto& t : th) t.join();
-  res->stats = rx_stats{};
+  {  // zero the statistics the caller's struct has room for
+    rx_stats z{};
+    const size_t off = offsetof(rx_result, stats), have = result_bytes(res);
+    if (have > off) memcpy(&res->stats, &z, std::min(sizeof(rx_stats), have - off));
+  }
   res->n_events = 0;
   res->events_overflow = 0;
   if (res->match_count_total) memset(res->match_count_total, 0, (size_t)size * sizeof(uint64_t));
@@ -1030,6 +1054,7 @@ extern "C" int rx_match_sharded(const rx_nfa* nfa, const uint8_t* bytes, size_t 
     res->stats.h2d_ms = std::max(res->stats.h2d_ms, x.r.stats.h2d_ms);
     res->stats.d2h_ms = std::max(res->stats.d2h_ms, x.r.stats.d2h_ms);
     res->stats.kernel_used = x.r.stats.kernel_used;
+    if (result_bytes(res) == sizeof(rx_result)) { res->stats.lanes_used = x.r.stats.lanes_used; res->stats.variant = x.r.stats.variant; }
     res->stats.n_launches += x.r.stats.n_launches;
     res->stats.tb_cycles += x.r.stats.tb_cycles;  // pairs never straddle shards when every shard is even-sized
   }

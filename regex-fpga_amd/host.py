@@ -41,7 +41,8 @@ class _Stats(C.Structure):
     _fields_ = [("n_passes", C.c_uint64), ("n_events", C.c_uint64), ("sum_active", C.c_uint64),
                 ("sum_edges", C.c_uint64), ("alg_bytes", C.c_uint64), ("kernel_ms", C.c_double),
                 ("h2d_ms", C.c_double), ("d2h_ms", C.c_double), ("kernel_used", C.c_uint32),
-                ("n_launches", C.c_uint32), ("tb_cycles", C.c_uint64)]
+                ("n_launches", C.c_uint32), ("tb_cycles", C.c_uint64), ("lanes_used", C.c_uint32),
+                ("variant", C.c_uint32)]
 
 
 class _Result(C.Structure):
@@ -292,7 +293,19 @@ class _Out:
                     stats=dict(n_passes=int(s.n_passes), n_events=int(s.n_events), sum_active=int(s.sum_active),
                                sum_edges=int(s.sum_edges), alg_bytes=int(s.alg_bytes), kernel_ms=s.kernel_ms,
                                h2d_ms=s.h2d_ms, d2h_ms=s.d2h_ms, kernel_used=int(s.kernel_used),
-                               n_launches=int(s.n_launches), tb_cycles=int(s.tb_cycles)))
+                               n_launches=int(s.n_launches), tb_cycles=int(s.tb_cycles), lanes_used=int(s.lanes_used),
+                               variant=_variant_name(s)))
+
+
+def _variant_name(s):
+    """Which build of the kernel ran, e.g. 'S13', 'S32+fold', 'G4', 'S8+prune' ('' for the wave kernels)."""
+    if not s.lanes_used:
+        return ""
+    v = ("G" if s.kernel_used == KERNEL_SYM_GROUP else "S") + str(s.lanes_used)
+    for bit, name in ((1, "stats"), (2, "prune"), (4, "fold")):
+        if s.variant & bit:
+            v += "+" + name
+    return v
 
 
 def _as_rows(data):

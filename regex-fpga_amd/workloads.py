@@ -93,8 +93,21 @@ def synthetic_ruleset(n=700, seed=20261004):
     return pats
 
 
-def ruleset_traffic(pats, n_streams, stream_len, first=0, seed=7):
-    """Printable pseudo-traffic with rule fragments mixed in (about one fragment per 40 bytes)."""
+def _ruleset_traffic_block(args):
+    pats, n_streams, stream_len, first, seed = args
+    return ruleset_traffic(pats, n_streams, stream_len, first=first, seed=seed)
+
+
+def ruleset_traffic(pats, n_streams, stream_len, first=0, seed=7, workers=1):
+    """Printable pseudo-traffic with rule fragments mixed in (about one fragment per 40 bytes).  Every stream has its
+    own seeded generator, so blocks can be produced by `workers` processes and any shard equals the same rows of the
+    whole batch."""
+    if workers > 1 and n_streams >= 4 * workers:
+        from concurrent.futures import ProcessPoolExecutor
+        per = (n_streams + workers - 1) // workers
+        jobs = [(pats, min(per, n_streams - b), stream_len, first + b, seed) for b in range(0, n_streams, per)]
+        with ProcessPoolExecutor(workers) as ex:
+            return np.concatenate(list(ex.map(_ruleset_traffic_block, jobs)))
     out = np.empty((n_streams, stream_len), np.uint8)
     frags = [p[:10] for p in pats[:64]] + _RULE_WORDS
     for i in range(n_streams):

@@ -428,6 +428,93 @@ def test_full_size_config3_properties(rx, orx, automata, traces, gpu_nfas, kerne
     assert np.array_equal(a["anymatch"][pick], ref["anymatch"])
 
 
+def _size_independent_checks(rx, nfa_size, a, ns):
+    """Invariants that need no oracle: canonical event order, counters = histogram of the events, any-match bits =
+    the passes of the events, every event inside the batch."""
+    ev = a["events"]
+    assert a["n_events"] == len(ev) and not a["events_overflow"]
+    order = np.lexsort((ev["state"], ev["k"], ev["stream"]))
+    assert np.array_equal(order, np.arange(len(ev)))
+    assert int(ev["stream"].max()) < ns
+    assert np.array_equal(np.bincount(ev["state"], minlength=nfa_size).astype(np.uint64), a["match_count_total"])
+    bits = np.zeros_like(a["anymatch"])
+    np.bitwise_or.at(bits, (ev["stream"], ev["k"] >> 5), (np.uint32(1) << (ev["k"] & 31)).astype(np.uint32))
+    assert np.array_equal(bits, a["anymatch"])
+
+
+def _oracle_sample_checks(orx, W, size, rows, a, n_pick, seed):
+    rng = np.random.default_rng(seed)
+    pick = np.sort(rng.choice(rows.shape[0], size=n_pick, replace=False))
+    ref = orx.match_batch(W, size, rows[pick], events_cap=1 << 22)
+    ev = a["events"]
+    sel = ev[np.isin(ev["stream"], pick)].copy()
+    sel["stream"] = np.searchsorted(pick, sel["stream"]).astype(np.uint32)
+    assert np.array_equal(sel, ref["events"].astype(sel.dtype))
+    assert np.array_equal(a["final_active"][pick], ref["final_active"])
+    assert np.array_equal(a["anymatch"][pick][:, :ref["anymatch"].shape[1]], ref["anymatch"])
+
+
+@pytest.mark.parametrize("workload", ["T", "U"])
+def test_baseline_configs3_per_gpu_shape(rx, orx, automata, traces, gpu_nfas, workload):
+    """BASELINE configs[3] at its per-GPU shape (1 Mi streams over 8 GPUs = 131 072 x 1 KB each), both seeded
+    distributions, generated as the block a middle rank owns: AUTO's choice == the wavefront-per-stream slice kernel ==
+    the north-star CSR kernel on every output, a seeded sample of 2 048 streams == the oracle, and the
+    size-independent invariants."""
+    W, size = automata["snort_16"]
+    wl = rx.workloads
+    ns, sl, first = 131072, 1024, 3 * 131072
+    rows = wl.trace_windows(traces[("snort_16", "lo")], traces[("snort_16", "hi")], ns, sl, first=first) if workload == "T" \
+        else wl.uniform(ns, sl, first=first)
+    a = rx.match(gpu_nfas["snort_16"], rows, kernel=rx.KERNEL_AUTO, events_cap=1 << 22)
+    assert rx.host.KERNEL_NAMES[a["stats"]["kernel_used"]] == "sym_pack"
+    for k in (dict(kernel=rx.KERNEL_SYM_WAVE), dict(kernel=rx.KERNEL_CSR_WAVE)):
+        b = rx.match(gpu_nfas["snort_16"], rows, **k, events_cap=1 << 22)
+        for f in ("events", "match_count_total", "anymatch", "final_active"):
+            assert np.array_equal(a[f], b[f]), (k, f)
+    if workload == "T":
+        assert a["n_events"] > 100000
+        _size_independent_checks(rx, size, a, ns)
+    else:
+        assert a["n_events"] == len(a["events"])
+    _oracle_sample_checks(orx, W, size, rows, a, 2048, 31)
+
+
+def test_baseline_configs4_snort16_on_4kb_windows(rx, orx, automata, traces, gpu_nfas):
+    """BASELINE configs[4] at its per-GPU shape with SURVEY 8(d)-5's PRIMARY stand-in: the shipped snort_16 table
+    (9 514 ~ 10k states) on 131 072 x 4 096-byte T windows (offset rule mod (200000 - 4096)), as rank 5 of 8 owns them.
+    AUTO == the wavefront-per-stream kernel on every output, oracle sample, invariants."""
+    W, size = automata["snort_16"]
+    wl = rx.workloads
+    ns, sl, first = 131072, 4096, 5 * 131072
+    rows = wl.trace_windows(traces[("snort_16", "lo")], traces[("snort_16", "hi")], ns, sl, first=first)
+    assert np.array_equal(rows[1], traces[("snort_16", "hi")][(((first + 1) >> 1) * 977) % (200000 - 4096):][:4096])
+    a = rx.match(gpu_nfas["snort_16"], rows, kernel=rx.KERNEL_AUTO, events_cap=1 << 22)
+    b = rx.match(gpu_nfas["snort_16"], rows, kernel=rx.KERNEL_SYM_WAVE, events_cap=1 << 22)
+    for f in ("events", "match_count_total", "anymatch", "final_active"):
+        assert np.array_equal(a[f], b[f]), f
+    assert a["n_events"] > 500000
+    _size_independent_checks(rx, size, a, ns)
+    _oracle_sample_checks(orx, W, size, rows, a, 512, 41)
+
+
+def test_baseline_configs4_ruleset_standin_per_gpu_shape(rx, orx):
+    """BASELINE configs[4], second stand-in, at the same per-GPU shape: the compiled 700-pattern rule set (10 396 states)
+    on 131 072 x 4 096 bytes of pseudo-traffic."""
+    wl = rx.workloads
+    pats = wl.synthetic_ruleset()
+    nfa = rx.Nfa.compile(pats)
+    ns, sl = 131072, 4096
+    rows = wl.ruleset_traffic(pats, ns, sl, first=2 * ns, workers=12)
+    assert np.array_equal(rows[:3], wl.ruleset_traffic(pats, 3, sl, first=2 * ns))
+    a = rx.match(nfa, rows, kernel=rx.KERNEL_AUTO, events_cap=1 << 22)
+    assert not a["events_overflow"]
+    b = rx.match(nfa, rows, kernel=rx.KERNEL_SYM_WAVE, events_cap=1 << 22)
+    for f in ("events", "match_count_total", "anymatch", "final_active"):
+        assert np.array_equal(a[f], b[f]), f
+    _size_independent_checks(rx, nfa.size, a, ns)
+    _oracle_sample_checks(orx, nfa.words, nfa.size, rows, a, 128, 43)
+
+
 def test_full_size_ruleset_standin(rx, orx):
     """BASELINE configs[4] stand-in at bench size (compiled 10 396-state rule set, 16 384 x 4 KB): AUTO's choice
     (pack kernel with look-ahead pruning) == the wavefront-per-stream kernel on every output, a seeded sample of

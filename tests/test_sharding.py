@@ -25,7 +25,7 @@ def test_shard_ranges(rx):
         sr(10, 2, 2)
 
 
-def _worker(rank, world, port, n_streams, stream_len, q):
+def _worker(rank, world, port, n_streams, stream_len, q, use_hip=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import importlib
@@ -40,9 +40,13 @@ def _worker(rank, world, port, n_streams, stream_len, q):
     W = orx.load_coe(wl.SNORT_COE)
     size = orx.infer_size(W)
     lo, hi = orx.load_mem(wl.TRACES[("snort_16", "lo")]), orx.load_mem(wl.TRACES[("snort_16", "hi")])
+    if use_hip:  # the product path: every rank loads the automaton file itself, uploads its own table, owns its plan
+        nfa = rx.Nfa.load_coe(wl.SNORT_COE)
+        matcher = lambda rows: rx.match(nfa, rows, device=0, kernel=rx.KERNEL_AUTO)  # noqa: E731
+    else:
+        matcher = lambda rows: orx.match_batch(W, size, rows, nthreads=1)  # noqa: E731
     first, count, res = rx.sharding.run_sharded(
-        lambda rows: orx.match_batch(W, size, rows, nthreads=1),
-        lambda f, c: wl.trace_windows(lo, hi, c, stream_len, first=f), n_streams, rank, world)
+        matcher, lambda f, c: wl.trace_windows(lo, hi, c, stream_len, first=f), n_streams, rank, world)
     dist.barrier()
     sec, ev, nbytes = rx.sharding.reduce_report(dist, torch.device("cpu"), 0.5 + rank, res["n_events"], count * stream_len)
     q.put((rank, first, count, res["events"], res["final_active"], sec, ev, nbytes))
@@ -76,6 +80,73 @@ def test_two_rank_gloo_equals_single_process(rx, orx):
     for g in got:  # every rank sees max time and global sums
         assert g[5] == 1.5 and g[6] == ref["n_events"] and g[7] == n_streams * stream_len
     assert ref["n_events"] > 0
+
+
+@pytest.mark.gpu
+def test_two_rank_gloo_with_the_hip_matcher_on_one_gpu(rx, orx):
+    """The N>1 path of bench.py with the REAL matcher: two processes (gloo for the report scalars), both on GPU 0, each
+    loading the automaton file, uploading its own table copy and matching only its contiguous block through the C-ABI;
+    the concatenation must equal the single-process oracle result.  (Two GPUs are not available to the tests; what can
+    be covered — two processes sharing one automaton file and one device, plan lifetimes, shard arithmetic — is.)"""
+    import torch.multiprocessing as mp
+    n_streams, stream_len, world = 4099, 700, 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_streams, stream_len, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    wl = rx.workloads
+    W = orx.load_coe(wl.SNORT_COE)
+    size = orx.infer_size(W)
+    lo, hi = orx.load_mem(wl.TRACES[("snort_16", "lo")]), orx.load_mem(wl.TRACES[("snort_16", "hi")])
+    ref = orx.match_batch(W, size, wl.trace_windows(lo, hi, n_streams, stream_len))
+    assert [(g[1], g[2]) for g in got] == [(0, 2050), (2050, 2049)]
+    ev = np.concatenate([g[3] for g in got])
+    assert np.array_equal(ev, ref["events"].astype(ev.dtype))
+    assert np.array_equal(np.concatenate([g[4] for g in got]), ref["final_active"])
+    for g in got:
+        assert g[5] == 1.5 and g[6] == ref["n_events"] > 0 and g[7] == n_streams * stream_len
+
+
+def _bench_self_launch(rx):
+    """`python bench.py --gpus 2` invoked directly (no torchrun around it) must start its ranks itself, before any
+    GPU call.  Here there is no GPU: the ranks start, fail at torch.cuda.set_device, and the launcher's failure comes
+    back — what matters is that the parent did not raise SystemExit('launch with torch.distributed.run')."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--streams-per-gpu", "64", "--stream-len", "64", "--dist-backend", "gloo", "--same-device",
+                        "--no-cpu-baseline", "--no-second-distribution"], env=env, capture_output=True, text=True, timeout=600)
+    blob = r.stdout + r.stderr
+    assert "launch with" not in blob
+    try:
+        have_gpu = rx.host.device_count() > 0
+    except rx.RxError:
+        have_gpu = False
+    if have_gpu:
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        import json
+        d = json.loads(line)
+        assert r.returncode == 0 and d["n_gpus"] == 2 and d["value"] > 0
+    else:
+        assert r.returncode != 0 and ("torch.distributed" in blob or "ChildFailedError" in blob or "rank" in blob.lower())
+
+
+def test_bench_starts_its_own_ranks(rx):
+    _bench_self_launch(rx)
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks_on_the_gpu(rx):
+    _bench_self_launch(rx)
 
 
 def test_workload_generators_are_shardable(rx, traces):

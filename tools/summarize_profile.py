@@ -2,7 +2,9 @@
 """Condense a tools/profile.sh output directory into the files kept under profiles/<name>/:
 kernel_stats.csv (rocprofv3 --kernel-trace --stats) and pmc_summary.json (per-launch means of every --pmc
 counter for the dominant kernel); optionally refresh profiles/traffic.json, which bench.py reads for
-roofline.traffic.   usage: summarize_profile.py gpurun_out/prof_<tag> profiles/<name> [traffic-key]"""
+roofline.traffic / roofline.pmc — keyed "<kernel>[:<variant>]:<workload>:<streams>x<len>" and stamped with the sha256
+of the kernel sources, so that bench.py reports it only for exactly the code that was profiled.
+usage: summarize_profile.py gpurun_out/prof_<tag> profiles/<name> [traffic-key]"""
 import collections
 import csv
 import glob
@@ -39,12 +41,36 @@ def main():
                            for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_WAVE_CYCLES") if k in c}
     json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
     print(short, "avg", out["kernel_trace_avg_ns"] / 1e6, "ms;", {k: round(v["mean_per_launch"]) for k, v in c.items()})
+    # figures bench.py copies into roofline.pmc (only while the kernel source is the one that was profiled)
+    t_s = out["kernel_trace_avg_ns"] * 1e-9
+    n_simd, clk = 1024, 2.4e9
+    pmc = {}
+    if "SQ_INSTS_VALU" in c:
+        pmc["valu_issue_frac"] = round(c["SQ_INSTS_VALU"]["mean_per_launch"] / (n_simd * clk * t_s / 2.0), 4)
+    if "SQ_INSTS_SALU" in c:
+        pmc["salu_issue_frac"] = round(c["SQ_INSTS_SALU"]["mean_per_launch"] / (256 * clk * t_s), 4)
+    if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
+        pmc["wave_cycles_waiting_frac"] = round(c["SQ_WAIT_ANY"]["mean_per_launch"] / c["SQ_WAVE_CYCLES"]["mean_per_launch"], 4)
+    if "SQ_LDS_BANK_CONFLICT" in c and "SQ_ACTIVE_INST_LDS" in c:
+        pmc["lds_conflict_cycles_per_lds_active_cycle"] = round(c["SQ_LDS_BANK_CONFLICT"]["mean_per_launch"] / c["SQ_ACTIVE_INST_LDS"]["mean_per_launch"], 4)
+    if "TCP_TCC_READ_REQ_sum" in c and "SQ_INSTS_VMEM_RD" in c:
+        pmc["l2_requests_per_vmem_read_instruction"] = round(c["TCP_TCC_READ_REQ_sum"]["mean_per_launch"] / c["SQ_INSTS_VMEM_RD"]["mean_per_launch"], 3)
+    if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+        pmc["l2_hit_rate"] = round(c["TCC_HIT_sum"]["mean_per_launch"] / (c["TCC_HIT_sum"]["mean_per_launch"] + c["TCC_MISS_sum"]["mean_per_launch"]), 4)
+    out["derived"] = pmc
+    json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
     if key and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         tj_path = os.path.join(os.path.dirname(os.path.abspath(dst)), "traffic.json")
         tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
         fetch = c["FETCH_SIZE"]["mean_per_launch"] * 1024.0   # counters are in KB
         write = c["WRITE_SIZE"]["mean_per_launch"] * 1024.0
+        import hashlib
+        h = hashlib.sha256()
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        for f in ("rx_kernels.hip", "rx_internal.hpp"):
+            h.update(open(os.path.join(root, "regex-fpga_amd", "csrc", f), "rb").read())
         tj[key] = {"hbm_bytes_per_launch": round(fetch + write), "fetch_bytes": round(fetch), "write_bytes": round(write),
+                   "src_sha16": h.hexdigest()[:16], "kernel_ms": round(out["kernel_trace_avg_ns"] / 1e6, 4), "pmc": pmc,
                    "source": f"{dst}/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, kernel {short} "
                              f"only; memset and resume kernels excluded)",
                    "note": "FETCH_SIZE/WRITE_SIZE are in KB. The gfx950 x2 correction of MI355X_MICROARCH.md applies to 16 B/lane "
