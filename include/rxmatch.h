@@ -132,6 +132,13 @@ enum {
                              construction cache lives in HBM per automaton and device, is grown on the device
                              and persists across launches (rx_nfa_dfa_reset clears it); sets it cannot hold
                              are handed to RX_KERNEL_SYM_WAVE.  Never chosen by RX_KERNEL_AUTO.             */
+  ,
+  RX_KERNEL_SYM_REG = 6   /* one wavefront per stream, the active set register-resident (one state per lane, updated
+                             in place: no LDS list, no filter), the always-on `.*` state folded out when the automaton
+                             has one: the kernel for FEW LONG streams — the reference's own run is one lock-step pair
+                             (testbench_BLK_Mem.sv:49-87).  RX_KERNEL_AUTO picks it for up to 4 streams from reset;
+                             more than 64 active states: hand-off to RX_KERNEL_SYM_WAVE.  With collect_stats or a
+                             caller-supplied start set RX_KERNEL_SYM_WAVE runs instead.                      */
 };
 
 typedef struct rx_opts {

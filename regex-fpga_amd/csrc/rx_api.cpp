@@ -71,6 +71,7 @@ struct DevTables {
   uint32_t* accept_bits = nullptr;
   uint32_t* symidx_c = nullptr;
   uint32_t *symidx_p = nullptr, *ovf_dir = nullptr;  // look-ahead pruning tables (pack kernel), may stay null
+  uint32_t* pin_tab = nullptr;                       // folding table of the pinned state (pack kernel), may stay null
   uint32_t* byte_class = nullptr;
   // lazy-DFA cache (allocated by the first RX_KERNEL_DFA launch)
   uint32_t *dfa_trans = nullptr, *dfa_pool = nullptr, *dfa_hash = nullptr, *dfa_hdr = nullptr;
@@ -174,6 +175,7 @@ extern "C" void rx_nfa_free(rx_nfa* nfa) {
     (void)hipFree(kv.second.symidx_c);
     (void)hipFree(kv.second.symidx_p);
     (void)hipFree(kv.second.ovf_dir);
+    (void)hipFree(kv.second.pin_tab);
     (void)hipFree(kv.second.byte_class);
     (void)hipFree(kv.second.dfa_trans);
     (void)hipFree(kv.second.dfa_pool);
@@ -251,6 +253,7 @@ static int get_dev_tables(const rx_nfa* cnfa, int device, DevTables* out) {
     if ((rc = upload_vec(nfa->h.symidx_p, &t.symidx_p))) return rc;
     if ((rc = upload_vec(nfa->h.ovf_dir, &t.ovf_dir))) return rc;
   }
+  if (!nfa->h.pin_tab.empty() && (rc = upload_vec(nfa->h.pin_tab, &t.pin_tab))) return rc;
   {
     std::vector<uint32_t> bc(64);
     memcpy(bc.data(), nfa->h.byte_class, 256);
@@ -368,6 +371,7 @@ struct rx_plan {
   uint32_t auto_kernel = RX_KERNEL_SYM_PACK;
   uint32_t auto_lanes = 16;    // streams per wavefront chosen for the pack kernel
   bool auto_prune = false;     // look-ahead pruning chosen (and verified at auto_lanes) by the probe
+  bool auto_fold = false;      // always-on-state folding chosen (and verified at auto_lanes) by the probe
   bool probe_prune = false;    // the probe's statistics say pruning pays (used when the caller fixes the kernel)
   double probe_active = 0;     // active states per stream-byte seen by the probe
   RxParams params{};
@@ -581,6 +585,8 @@ static void fill_common(rx_plan* p, RxParams& a) {
   a.symidx_p = p->tab.symidx_p;
   a.ovf_dir = p->tab.ovf_dir;
   a.byte_class = p->tab.byte_class;
+  a.pin_tab = p->tab.pin_tab;
+  a.pin_cols = h.n_classes + 1u;
   a.n_classes = h.n_classes;
   a.size = h.size;
   a.bytes = p->d_in;
@@ -612,12 +618,14 @@ static int auto_probe(rx_plan* p) {
   p->auto_kernel = RX_KERNEL_SYM_PACK;
   p->auto_lanes = 16;
   p->auto_prune = false;
+  p->auto_fold = false;
   p->probe_prune = false;
   p->probe_active = 0;
   if (p->n_streams * p->stream_len < (256u << 10)) return RX_OK;  // tiny batch: not worth a probe
   // one run of the pack kernel with `lanes` streams per wavefront over the corner of the batch: the statistics
   // build (counters) or, with stats = false, the build that would really run (only the hand-off count is read)
   unsigned long long cnt[16];
+  bool run_fold = false;  // the next run() uses the FOLD build
   auto run = [&](uint32_t lanes, bool stats, bool prune, double* spilled) -> int {
     RxParams a;
     fill_common(p, a);
@@ -631,6 +639,7 @@ static int auto_probe(rx_plan* p) {
     if (rc) return rc;
     cfg.stats = stats;
     cfg.prune = prune;
+    cfg.fold = run_fold && !stats;
     if ((rc = ensure_spill_area(p, a))) return rc;
     HIPCHK(hipMemsetAsync(p->d_counters, 0, 16 * sizeof(unsigned long long), p->stream));
     hipError_t e = (hipError_t)rx_launch(a, cfg, p->stream);
@@ -676,6 +685,27 @@ static int auto_probe(rx_plan* p) {
   // (pruning must remove at least a tenth of the entries to pay for its directory look-ups: l7-filter meets
   // multi-target rows in every pass but nearly all of their targets live on)
   p->probe_prune = p->tab.ovf_dir && (double)cnt[5] / own >= 0.02 && (double)cnt[6] / own >= 0.10;
+  // Always-on-state folding (automata whose state 0 enters a `.*` state on every byte): that state leaves the lists, and
+  // of its targets only those that survive the next byte enter them.  The FOLD build pays a fixed price per pass for
+  // the folded state's table look-ups and wins when the lists are nearly empty afterwards (measured, snort_16, one
+  // MI355X: uniform bytes 0.006 entries left per stream-byte: 65 536 streams 1 050 -> 1 430 Gbit/s, 131 072 streams
+  // 1 120 -> 2 210 Gbit/s; trace windows 1.1 left: 505 -> 476 Gbit/s, no gain) — so the probe runs it on the sample,
+  // reads how many entries were left, and takes it below 0.3 per stream-byte.  Streams per wavefront: as many as still
+  // give every SIMD two wavefronts (16 ... 64).
+  if (p->tab.pin_tab && !(p->opts.flags & RX_OPT_NO_FOLD) && active <= 3.0) {
+    const bool prune = p->probe_prune && !(p->opts.flags & RX_OPT_NO_PRUNE);
+    run_fold = true;
+    rc = run(32, false, prune, &spilled);
+    run_fold = false;
+    if (rc) return rc;
+    const double left = (double)cnt[7] / units;
+    static const uint32_t fold_s[] = {16, 24, 32, 48, 64};
+    uint32_t lanes = 16;
+    for (uint32_t c : fold_s) if ((double)c <= per_simd / 2.0) lanes = c;
+    if (dbg) fprintf(stderr, "[rxmatch] probe: folded build leaves %.3f list entries per stream-byte, hand-offs %.1f %% -> %s\n", left,
+                     100.0 * spilled, (left <= 0.3 && spilled <= 0.02) ? "fold" : "no fold");
+    if (left <= 0.3 && spilled <= 0.02) { p->auto_lanes = lanes; p->auto_fold = true; p->auto_prune = prune; return RX_OK; }
+  }
   if (p->probe_prune && !(p->opts.flags & RX_OPT_NO_PRUNE)) {
     const double entries = active * (1.0 - (double)cnt[6] / own);
     if (entries <= 6.0) {
@@ -730,6 +760,9 @@ extern "C" int rx_plan_launch(rx_plan* p) {
     kernel = RX_KERNEL_SYM_PACK;
   }
   a.pair_cycles = pair ? 1u : 0u;
+  // few long streams from reset (the reference's own run is one lock-step pair): latency per pass is what counts, and the
+  // register-resident kernel has the shortest pass; it has no statistics build
+  if (kernel == RX_KERNEL_AUTO && p->n_streams <= 4 && p->opts.collect_stats == 0 && !p->have_init) kernel = RX_KERNEL_SYM_REG;
   // the probe also serves an explicit RX_KERNEL_SYM_PACK: whether look-ahead pruning pays depends on the input
   const bool probe_for_pack = kernel == RX_KERNEL_SYM_PACK && p->tab.ovf_dir && p->opts.collect_stats == 0;
   if ((kernel == RX_KERNEL_AUTO || probe_for_pack) && !pair && !p->have_init) {
@@ -737,8 +770,8 @@ extern "C" int rx_plan_launch(rx_plan* p) {
       if ((rc = auto_probe(p))) return rc;
       p->auto_decided = true;
       if (p->opts.flags & RX_OPT_VERBOSE)
-        fprintf(stderr, "[rxmatch] AUTO -> kernel %u, %u streams per wavefront, look-ahead pruning %s\n", p->auto_kernel,
-                p->auto_lanes, p->auto_prune ? "on" : "off");
+        fprintf(stderr, "[rxmatch] AUTO -> kernel %u, %u streams per wavefront, look-ahead pruning %s, folding %s\n",
+                p->auto_kernel, p->auto_lanes, p->auto_prune ? "on" : "off", p->auto_fold ? "on" : "off");
     }
     if (kernel == RX_KERNEL_AUTO) {
       kernel = p->auto_kernel;
@@ -747,12 +780,27 @@ extern "C" int rx_plan_launch(rx_plan* p) {
   }
   // a caller-supplied start set is a bitmask row: that is the wave kernel's dense form
   if (p->have_init && (kernel == RX_KERNEL_AUTO || kernel == RX_KERNEL_SYM_GROUP || kernel == RX_KERNEL_SYM_PACK ||
-                       kernel == RX_KERNEL_DFA))
+                       kernel == RX_KERNEL_DFA || kernel == RX_KERNEL_SYM_REG))
     kernel = RX_KERNEL_SYM_WAVE;
+  if (kernel == RX_KERNEL_SYM_REG && p->opts.collect_stats != 0) kernel = RX_KERNEL_SYM_WAVE;
   p->cfg.group_lanes = auto_lanes ? auto_lanes : p->opts.group_lanes;
   rc = rx_pick_launch(kernel, h.size, a.n_streams, p->tab.cu_count, p->tab.lds_per_cu, &a, &p->cfg);
   if (rc) return rc;
   p->cfg.stats = p->opts.collect_stats != 0;
+  // always-on-state folding: AUTO's verified choice; an explicit RX_KERNEL_SYM_PACK folds only on RX_OPT_FORCE_FOLD (its
+  // group_lanes then names one of the FOLD builds: 8/13/16/24/32/48/64 streams per wavefront)
+  p->cfg.fold = p->tab.pin_tab != nullptr && !p->cfg.stats && !p->have_init && !(p->opts.flags & RX_OPT_NO_FOLD) &&
+                ((p->cfg.kernel == RX_KERNEL_SYM_PACK &&
+                  ((p->opts.flags & RX_OPT_FORCE_FOLD) != 0 || (p->opts.kernel == RX_KERNEL_AUTO && p->auto_fold))) ||
+                 p->cfg.kernel == RX_KERNEL_SYM_REG);  // the register kernel folds whenever the automaton allows
+  if (p->cfg.fold && p->cfg.kernel == RX_KERNEL_SYM_PACK) {
+    static const uint32_t fold_s[] = {8, 13, 16, 24, 32, 48, 64};
+    uint32_t pick = 64;
+    for (uint32_t c : fold_s) if (p->cfg.group_lanes <= c) { pick = c; break; }
+    p->cfg.group_lanes = pick;
+  } else if (p->cfg.kernel == RX_KERNEL_SYM_PACK && p->cfg.group_lanes > 32) {
+    p->cfg.group_lanes = 32;
+  }
   p->cfg.verbose = (p->opts.flags & RX_OPT_VERBOSE) != 0;
   p->cfg.profile_pack = (p->opts.flags & RX_OPT_PROFILE_PACK) != 0;
   // look-ahead pruning of multi-target rows follows the probe: AUTO's verified choice, or for an explicit
@@ -762,7 +810,7 @@ extern "C" int rx_plan_launch(rx_plan* p) {
                  ((p->opts.flags & RX_OPT_FORCE_PRUNE) != 0 ||
                   (p->opts.kernel == RX_KERNEL_SYM_PACK ? p->probe_prune : p->opts.kernel == RX_KERNEL_AUTO && p->auto_prune));
   const bool two_tier = p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK ||
-                        p->cfg.kernel == RX_KERNEL_DFA;
+                        p->cfg.kernel == RX_KERNEL_DFA || p->cfg.kernel == RX_KERNEL_SYM_REG;
   if (two_tier && (rc = ensure_spill_area(p, a))) return rc;
   if (p->cfg.kernel == RX_KERNEL_DFA) {
     if (pair) return RX_EINVAL;
@@ -882,15 +930,19 @@ static int plan_download(rx_plan* p, rx_result* res) {
       fprintf(stderr, "[rxmatch] pack pass phase %d %-44s %5.1f %%  (%.0f cycles per wave-pass)\n", q, names[q],
               100.0 * cnt[8 + q] / tot, (double)cnt[8 + q] / ((double)((p->n_streams + 15) / 16) * p->params.n_passes));
   }
+  if ((p->opts.flags & RX_OPT_VERBOSE) && p->cfg.kernel == RX_KERNEL_SYM_REG && cnt[9])
+    fprintf(stderr, "[rxmatch] register kernel, stream 0: %llu shader cycles in %.3f ms = %.0f MHz, %.0f cycles per pass\n", cnt[8],
+            cnt[9] * 1e-5, (double)cnt[8] / cnt[9] * 100.0, (double)cnt[8] / std::max<uint32_t>(p->params.n_passes, 1));
   st.n_passes = p->params.n_passes;
   st.n_events = cnt[0];
   st.kernel_ms = p->last_ms;
   st.kernel_used = p->cfg.kernel;
   st.lanes_used = (p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK) ? p->cfg.group_lanes : 0u;
   st.variant = (p->cfg.stats ? RX_VARIANT_STATS : 0u) |
-               (p->cfg.kernel == RX_KERNEL_SYM_PACK && p->cfg.prune && !p->cfg.stats ? RX_VARIANT_PRUNE : 0u);
+               (p->cfg.kernel == RX_KERNEL_SYM_PACK && p->cfg.prune && !p->cfg.stats && p->tab.ovf_dir ? RX_VARIANT_PRUNE : 0u) |
+               (p->cfg.fold ? RX_VARIANT_FOLD : 0u);
   st.n_launches = (p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK ||
-                   p->cfg.kernel == RX_KERNEL_DFA) ? 2 : 1;
+                   p->cfg.kernel == RX_KERNEL_DFA || p->cfg.kernel == RX_KERNEL_SYM_REG) ? 2 : 1;
   if (p->cfg.stats) {
     st.sum_active = cnt[1];
     st.sum_edges = cnt[2];

@@ -279,5 +279,116 @@ int rxh_build(const uint32_t* W, size_t nwords, uint32_t size_or_0, RxHostNfa* o
       out->ovf_dir.clear();
     }
   }
+  // ---- always-on-state folding (pack kernel FOLD builds) ----------------------------------------------------------
+  // The pinned state loops on every byte, so once a stream holds it it holds it forever; when state 0 enters it on
+  // EVERY byte, every stream that starts from reset (FPGA.v:134-147) holds it from pass 1 on.  Such a state need not be
+  // a list entry: what its row emits on a byte is a function of the byte alone — and, with one byte of look-ahead, only
+  // the targets that are accept states or have an edge on the NEXT byte need to be inserted (the others can neither
+  // pulse nor produce a successor; the sets that are REPORTED are built from the unpruned column).  snort_16: state 1
+  // starts 34 patterns; on the shipped traces 2.4 list entries per stream-byte become 1.1, on uniform bytes 1.1 -> 0.01.
+  out->pin_tab.clear();
+  if (pin != 0xFFFFFFFFu) {
+    const uint32_t ncls = out->n_classes;
+    bool all = true;  // state 0 --every byte--> pin
+    for (uint32_t k = 0; k < ncls && all; k++) {
+      const uint32_t w = out->symidx_c[k];  // row of state 0
+      bool has = (w & RXE_INLINE) && (w & RXE_PIN);
+      if (!has && (w & RXE_OVF)) {
+        const uint32_t off = w & RXE_TGT_MASK;
+        for (uint32_t j = 0; j < out->ovf[off] && !has; j++) has = (out->ovf[off + 1u + j] & RXE_PIN) != 0;
+      }
+      all = has;
+    }
+    bool ok = all && pin != 0 && (uint64_t)ncls * (ncls + 1u) * 4u <= 48u * 1024u;  // the table lives in LDS
+    std::vector<uint32_t> tab((size_t)ncls * (ncls + 1u), 0u), tg, sub;
+    for (uint32_t k = 0; k < ncls && ok; k++) {
+      const uint32_t w = out->symidx_c[(size_t)pin * ncls + k];  // pin's slice on class k (RXE_SELF set by definition)
+      tg.clear();
+      if (w & RXE_INLINE) tg.push_back(w & RXE_TGT_MASK);
+      if (w & RXE_OVF) {
+        const uint32_t off = w & RXE_TGT_MASK;
+        for (uint32_t j = 0; j < out->ovf[off]; j++) tg.push_back(out->ovf[off + 1u + j] & RXE_TGT_MASK);
+      }
+      for (uint32_t n = 0; n <= ncls && ok; n++) {
+        sub.clear();
+        for (uint32_t t : tg)
+          if (n == ncls || is_acc(t) || out->symidx_c[(size_t)t * ncls + n] != 0u) sub.push_back(t);
+        uint32_t ent = 0;
+        if (sub.size() == 1) {
+          ent = RXE_INLINE | sub[0] | (is_acc(sub[0]) ? RXE_ACCEPT : 0u);
+        } else if (sub.size() >= 2) {
+          auto it = ovf_at.find(sub);
+          if (it == ovf_at.end()) {
+            const size_t o2 = out->ovf.size();
+            if (o2 + sub.size() + 1 > RXE_TGT_MASK) { ok = false; break; }
+            out->ovf.push_back((uint32_t)sub.size());
+            for (uint32_t t : sub) out->ovf.push_back(t | (is_acc(t) ? RXE_ACCEPT : 0u) | pin_flag(t));
+            it = ovf_at.emplace(sub, (uint32_t)o2).first;
+          }
+          ent = RXE_OVF | it->second;
+        }
+        tab[(size_t)k * (ncls + 1u) + n] = ent;
+      }
+    }
+    if (ok) out->pin_tab.swap(tab);
+  }
+  // ---- RXE_MAYDUP: which insertions can meet a duplicate -----------------------------------------------------------
+  // For every (target, class): the number of distinct states with an edge to the target on that class (the target
+  // itself counts when it loops on the class).  States nothing leads to (state 0) are active in pass 0 only, alone, and
+  // do not count.  Fewer than two => a duplicate-free set S_k cannot produce the target twice.
+  {
+    const uint32_t ncls = out->n_classes;
+    const size_t cells = (size_t)size * ncls;
+    std::vector<uint8_t> np;
+    const bool exact = cells <= ((size_t)256 << 20);
+    if (exact) {
+      np.assign(cells, 0);
+      std::vector<uint8_t> entered(size, 0);
+      for (uint32_t e = 0; e < out->nnz; e++) entered[col[e] & 0xFFFFFFu] = 1;
+      auto bump = [&](uint32_t t, uint32_t k) { uint8_t& c = np[(size_t)t * ncls + k]; if (c < 2) c++; };
+      for (uint32_t i = 0; i < size; i++) {
+        if (!entered[i]) continue;
+        for (uint32_t k = 0; k < ncls; k++) {
+          const uint32_t w = out->symidx_c[(size_t)i * ncls + k];
+          if (w & RXE_SELF) bump(i, k);
+          if (w & RXE_INLINE) bump(w & RXE_TGT_MASK, k);
+          if (w & RXE_OVF) {
+            const uint32_t off = w & RXE_TGT_MASK;
+            for (uint32_t j = 0; j < out->ovf[off]; j++) bump(out->ovf[off + 1u + j] & RXE_TGT_MASK, k);
+          }
+        }
+      }
+    }
+    auto dup = [&](uint32_t t, uint32_t k) { return !exact || np[(size_t)t * ncls + k] >= 2; };
+    auto flag_list = [&](uint32_t off, uint32_t k) {  // lists are shared between slices: flags accumulate (conservative)
+      for (uint32_t j = 0; j < out->ovf[off]; j++)
+        if (dup(out->ovf[off + 1u + j] & RXE_TGT_MASK, k)) out->ovf[off + 1u + j] |= RXE_MAYDUP;
+    };
+    const bool have_dir = !out->ovf_dir.empty();
+    for (uint32_t i = 0; i < size; i++)
+      for (uint32_t k = 0; k < ncls; k++) {
+        const size_t at = (size_t)i * ncls + k;
+        const uint32_t w = out->symidx_c[at];
+        if ((w & RXE_INLINE) && dup(w & RXE_TGT_MASK, k)) {
+          out->symidx_c[at] |= RXE_MAYDUP;
+          if (have_dir) out->symidx_p[at] |= RXE_MAYDUP;
+        }
+        if (w & RXE_OVF) {
+          flag_list(w & RXE_TGT_MASK, k);
+          if (have_dir) {
+            const uint32_t* dir = &out->ovf_dir[(size_t)(out->symidx_p[at] & RXE_TGT_MASK) * (ncls + 1u)];
+            for (uint32_t n = 0; n <= ncls; n++)
+              if (dir[n]) flag_list(dir[n] >> 8, k);
+          }
+        }
+      }
+    if (!out->pin_tab.empty())
+      for (uint32_t k = 0; k < ncls; k++)
+        for (uint32_t n = 0; n <= ncls; n++) {
+          uint32_t& w = out->pin_tab[(size_t)k * (ncls + 1u) + n];
+          if ((w & RXE_INLINE) && dup(w & RXE_TGT_MASK, k)) w |= RXE_MAYDUP;
+          if (w & RXE_OVF) flag_list(w & RXE_TGT_MASK, k);
+        }
+  }
   return RX_OK;
 }

@@ -21,6 +21,11 @@ static constexpr uint32_t RXE_ACCEPT = 0x40000000u;
 static constexpr uint32_t RXE_SELF = 0x20000000u;
 static constexpr uint32_t RXE_OVF = 0x10000000u;
 static constexpr uint32_t RXE_PIN = 0x08000000u;   // target is the pinned state (see RxHostNfa::pin_state)
+// The target can be reached on this byte class from a SECOND state that may be active at the same time (another
+// predecessor on the class, or itself through a self-loop): only such a target can already be in the next set when it
+// is inserted.  Per-class index, overflow lists and the folding table carry the flag; kernels that deduplicate every
+// insertion through a filter ignore it, the register-resident single-stream kernel checks only flagged targets.
+static constexpr uint32_t RXE_MAYDUP = 0x04000000u;
 static constexpr uint32_t RXE_TGT_MASK = 0x00FFFFFFu;
 
 // Active-list entry (LDS): state id in bits 23:0, RXE_ACCEPT if the state is an accept state.
@@ -42,6 +47,12 @@ struct RxParams {
   // that survive a next byte of class c, entry n_classes = the full list.  Both null when there is nothing to prune.
   const uint32_t* symidx_p;
   const uint32_t* ovf_dir;
+  // always-on-state folding (pack kernel FOLD builds, see rx_host.cpp): what the pinned `.*` state's row emits on a byte
+  // of class c when the stream's next byte has class n — pin_tab[c * pin_cols + n], column n_classes = no look-ahead (the
+  // full slice).  Entry: 0 | RXE_INLINE|target[|RXE_ACCEPT] | RXE_OVF|offset into `ovf`.  Null when the automaton has no
+  // foldable state.
+  const uint32_t* pin_tab;
+  uint32_t pin_cols;            // n_classes + 1
   const uint32_t* byte_class;   // [64] words = 256 bytes: class id of every input byte
   uint32_t n_classes;
   const uint32_t* ovf;          // overflow target lists of the slice index
@@ -104,8 +115,10 @@ struct RxLaunchCfg {
   uint32_t grid_blocks;
   uint32_t lds_bytes;      // dynamic LDS per block
   int cu_count;
+  size_t lds_per_cu;
   bool stats;
   bool prune;              // SYM_PACK: look-ahead pruning of multi-target rows (needs RxParams::ovf_dir)
+  bool fold;               // SYM_PACK: the pinned `.*` state is folded out of the lists (needs RxParams::pin_tab)
   bool verbose;            // rx_opts.flags & RX_OPT_VERBOSE: print the launch geometry
   bool profile_pack;       // rx_opts.flags & RX_OPT_PROFILE_PACK: stamped diagnostic build of the pack kernel (S=16)
 };
@@ -132,6 +145,9 @@ struct RxHostNfa {
   uint32_t pin_state = 0xFFFFFFFFu;
   // look-ahead pruning tables (RxParams::symidx_p / ovf_dir); empty when the automaton has no multi-target rows
   std::vector<uint32_t> symidx_p, ovf_dir;
+  // folding table of the pinned state (RxParams::pin_tab), n_classes * (n_classes + 1) words; empty unless state 0
+  // enters the pinned state on every byte (then every stream that starts from reset holds it from pass 1 on)
+  std::vector<uint32_t> pin_tab;
   const uint32_t* row_ptr() const { return words.data(); }
   const uint32_t* col() const { return words.data() + size + 1; }
 };

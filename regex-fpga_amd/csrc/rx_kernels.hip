@@ -30,6 +30,7 @@
 // No MFMA anywhere: this is integer gather / bit-scatter.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -758,19 +759,21 @@ __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
 //     only the targets that survive the stream's next byte;
 //   * next list would exceed the layout's CAPW => all S streams are handed to the wave kernel (resume);
 //   * the passes run in chunked loops (refill per 64, bitmap store per 32, mode as a compile-time tag).
-template <int S, bool PRUNE>
+template <int S, bool PRUNE, bool FOLD>
 struct PackLayout {
   // few streams per wavefront = automata/inputs with many active states per stream: longer list, wider filters
-  static constexpr uint32_t FW = S <= 4 ? 2u * RX_GROUP_FILTER_WORDS : RX_GROUP_FILTER_WORDS;
+  // (FOLD builds keep the always-on state out of the lists: about one entry per stream is left, half the filter does)
+  static constexpr uint32_t FW = S <= 4 ? 2u * RX_GROUP_FILTER_WORDS : (FOLD ? RX_GROUP_FILTER_WORDS / 2u : RX_GROUP_FILTER_WORDS);
   // (the PRUNE build serves automata with bursts of active states: twice the list for up to 13 streams per wavefront)
-  static constexpr uint32_t CAPW = S <= 4 ? 512u : (PRUNE && S <= 13 ? 2u * RX_PACK_CAP : RX_PACK_CAP);
-  // 64 input bytes (as byte classes) per stream; PRUNE: + byte 64 = first class of the next chunk (look-ahead at
-  // the window's last byte) + a pad word that keeps the stride odd
-  static constexpr uint32_t WINW = PRUNE ? 18 : 16;
+  static constexpr uint32_t CAPW = S <= 4 ? 512u : (PRUNE && S <= 13 ? 2u * RX_PACK_CAP : (S >= 48 ? 256u : RX_PACK_CAP));
+  // 64 input bytes (as byte classes) per stream; look-ahead builds (PRUNE, FOLD): + byte 64 = first class of the next
+  // chunk (look-ahead at the window's last byte) + a pad word that keeps the stride odd
+  static constexpr uint32_t WINW = (PRUNE || FOLD) ? 18 : 16;
   static constexpr uint32_t STRIDE = 2u * FW + WINW + 1u;   // + any-match word; odd => banks spread
   static constexpr uint32_t LISTW = CAPW + 128u;            // a sweep appends at most 128 entries past CAPW: no bounds check
   static constexpr uint32_t WAVE_WORDS = 2u * LISTW + S * STRIDE + S;  // lists, stream regions, spill slots
   static constexpr uint32_t CMAPW = 64;                     // byte -> class map (256 bytes), shared by the block
+  // FOLD: the block also keeps the pinned state's folding table (RxParams::pin_tab) behind the class map
 };
 
 // PROF: diagnostic build only (RX_PROFILE_PACK=1): s_memtime stamps around the phases of a pass; the sums go to
@@ -779,9 +782,14 @@ struct PackLayout {
 // byte.  The statistics build counts every active state of the reference's sets, so it always runs unpruned; it marks
 // the entries that came out of multi-target rows (bit 29) and counts those that die at once, which is what AUTO
 // needs to know to pick PRUNE and the streams per wavefront that go with it.
-template <int S, bool STATS, bool PROF, bool PRUNE>
-__global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
-  static_assert(!(PRUNE && (STATS || PROF)), "statistics / stamped builds run unpruned");
+// FOLD: always-on-state folding (rx_host.cpp) — the pinned `.*` state is no list entry: every stream from reset holds it
+// from pass 1 on, and what its row emits on the current byte comes from a (class x next class) table in LDS, looked
+// up by the stream's OWNER lane while the list entries' slice gather is in flight; of its targets only those that are
+// accept states or survive the next byte are inserted.  Six-bit stream slots (up to 64 streams per wavefront).
+template <int S, bool STATS, bool PROF, bool PRUNE, bool FOLD>
+__global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxParams p) {
+  static_assert(!((PRUNE || FOLD) && (STATS || PROF)), "statistics / stamped builds run unpruned and unfolded");
+  constexpr bool LOOK = PRUNE || FOLD;  // the window carries one byte of look-ahead
   constexpr uint32_t MARK = 1u << 29;  // STATS only: entry was inserted from a multi-target row
   unsigned long long t_prev = 0, t_sum[7] = {0, 0, 0, 0, 0, 0, 0};
   auto stamp = [&](int phase) {
@@ -792,16 +800,18 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       t_prev = t;
     }
   };
-  using L = PackLayout<S, PRUNE>;
+  using L = PackLayout<S, PRUNE, FOLD>;
   constexpr uint32_t HMASK = 32u * L::FW - 1u;
-  constexpr uint32_t SID_SHIFT = 24, SID_MASK = 31u << SID_SHIFT;
+  constexpr uint32_t SID_SHIFT = 24, SID_BITS = FOLD ? 63u : 31u, SID_MASK = SID_BITS << SID_SHIFT;
   constexpr uint32_t KEY_MASK = RXE_TGT_MASK | SID_MASK;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wib = threadIdx.x >> 6, wpb = blockDim.x >> 6;
   uint32_t* cmapw = lds;                              // [64] byte -> class
   const uint8_t* cmap = reinterpret_cast<const uint8_t*>(cmapw);
-  uint32_t* wl = lds + L::CMAPW + (size_t)wib * L::WAVE_WORDS;  // [2][CAPW] wave-wide lists
+  const uint32_t pin_words = FOLD ? p.n_classes * p.pin_cols : 0u;
+  const uint32_t* pintab = lds + L::CMAPW;           // FOLD: [n_classes][n_classes + 1], shared by the block
+  uint32_t* wl = lds + L::CMAPW + pin_words + (size_t)wib * L::WAVE_WORDS;  // [2][CAPW] wave-wide lists
   uint32_t* sreg0 = wl + 2u * L::LISTW;              // [S][STRIDE]: filters[2][FW], window[WINW], am word
   uint32_t* slotw = sreg0 + S * L::STRIDE;           // [S] spill slots
   const uint32_t* __restrict__ rp = p.words;
@@ -809,9 +819,11 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
   const uint32_t* __restrict__ symidx = PRUNE ? p.symidx_p : p.symidx_c;
   const uint32_t ncls = p.n_classes;
   const uint32_t* __restrict__ ovf = p.ovf;
-  unsigned long long st_active = 0, st_edges = 0, st_cost = 0, st_ovf = 0, st_dead = 0;
+  unsigned long long st_active = 0, st_edges = 0, st_cost = 0, st_ovf = 0, st_dead = 0, fold_entries = 0;
 
   for (uint32_t w = threadIdx.x; w < L::CMAPW; w += blockDim.x) cmapw[w] = p.byte_class[w];
+  if (FOLD)
+    for (uint32_t w = threadIdx.x; w < pin_words; w += blockDim.x) lds[L::CMAPW + w] = p.pin_tab[w];
   __syncthreads();  // the only block-wide barrier; the waves never meet again
 
   const uint32_t wave = blockIdx.x * wpb + wib;
@@ -820,7 +832,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
   const uint32_t n_mine = p.n_streams - stream0 < (uint32_t)S ? p.n_streams - stream0 : (uint32_t)S;
   const bool owner = lane < n_mine;  // lane == stream slot it owns
   // input windows: lane = 4*slot + part fetches bytes [64*chunk + 16*part, +16) of stream `slot`
-  static_assert(S >= 1 && S <= 32, "five-bit stream slot; the window loader covers 16 streams per wave-load");
+  static_assert(S >= 1 && S <= (FOLD ? 64 : 32), "five-bit (FOLD: six-bit) stream slot; the window loader covers 16 streams per wave-load");
   constexpr uint32_t NLOAD = (S + 15) / 16;  // wave-loads per refill
   auto load_win = [&](uint32_t chunk, uint32_t (&o)[NLOAD][4]) {
 #pragma unroll
@@ -946,16 +958,50 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       }
     };
 
+    // FOLD, part 1: every stream from reset holds the pinned state from pass 1 on.  Its owner lane looks up what that
+    // state's row emits on this byte, already reduced to the targets that survive the NEXT byte (full slice at the
+    // stream's last byte, whose sets are reported).  Two dependent LDS reads that do not depend on the list: they are
+    // in flight while the sweep below reads its entries, and the insertion (part 2) runs in the shadow of the gather.
+    uint32_t vA = 0u;
+    const bool pin_now = FOLD && consume && k >= 1u;  // wave-uniform
+    if (pin_now && owner) {
+      const uint8_t* wb = reinterpret_cast<const uint8_t*>(sreg0 + lane * L::STRIDE + 2u * L::FW);
+      const uint32_t c0 = wb[kk];
+      const uint32_t sel = (k + 1u < p.n_consume) ? (uint32_t)wb[kk + 1u] : ncls;  // byte 64 of the window: stash
+      vA = pintab[c0 * p.pin_cols + sel];
+    }
+    bool pin_done = !pin_now;
+    auto pin_stage = [&]() {  // FOLD, part 2; wave-uniform call
+      pin_done = true;
+      uint32_t* oreg = sreg0 + lane * L::STRIDE;  // (lanes that own no stream pass pred = false)
+      if (wballot(vA & RXE_INLINE))
+        insert((vA & RXE_INLINE) != 0u, (vA & (RXE_TGT_MASK | RXE_ACCEPT)) | (lane << SID_SHIFT), oreg);
+      uint64_t mo = wballot(vA & RXE_OVF);  // several pattern heads on this byte survive the next one: rare
+      while (mo) {
+        const uint32_t src = (uint32_t)__builtin_ctzll(mo);
+        mo &= mo - 1;
+        const uint32_t off = bcast(vA & RXE_TGT_MASK, src);
+        const uint32_t cnt = ovf[off];
+        uint32_t* sr = sreg0 + src * L::STRIDE;
+        for (uint32_t q0 = 0; q0 < cnt; q0 += 64u) {
+          const bool act = q0 + lane < cnt;
+          const uint32_t w = act ? ovf[off + 1u + q0 + lane] : 0u;
+          insert(act && !(w & RXE_PIN), (w & (RXE_TGT_MASK | RXE_ACCEPT)) | (src << SID_SHIFT), sr);
+        }
+      }
+    };
+
     // Predicates are kept as integer tests taken right at the ballot (one v_and + v_cmp each): a bool assembled from
     // several flags reaches __ballot through a VGPR (v_cndmask + v_cmp), and this loop is bound by instruction issue.
     constexpr uint32_t E_NONE = 0x80000000u;  // list-entry flag of a lane without an entry (bit 31 is otherwise unused)
     const uint32_t Ns = (uint32_t)__builtin_amdgcn_readfirstlane((int)N);  // wave-uniform: keep the loop scalar
+    if (FOLD && consume) fold_entries += Ns;  // (scalar) what AUTO's probe reads: list entries left per stream-byte
     for (uint32_t b0 = 0; b0 < Ns; b0 += 64u) {
       const uint32_t li = b0 + lane;
       uint32_t e = clist[li];  // lanes past N read harmless LDS words of this wave and are overwritten below
       if (li >= Ns) e = e_none;
       if (PROF) { asm volatile("" ::"v"(e)); stamp(0); }  // phase 0: refill check + list read
-      const uint32_t sid = (e >> SID_SHIFT) & 31u;
+      const uint32_t sid = (e >> SID_SHIFT) & SID_BITS;
       const uint32_t s = e & RXE_TGT_MASK;
       uint32_t* sreg = sreg0 + sid * L::STRIDE;
       {  // accept pulses
@@ -1004,6 +1050,11 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
         if ((e & MARK) && live && x == 0u) st_dead += 1;  // came out of a multi-target row and dies at once
       }
       const uint32_t e_keep = STATS ? e & ~MARK : e;
+      if (FOLD && !pin_done) {  // the gather is in flight: insert what the folded state emits meanwhile
+        __builtin_amdgcn_sched_barrier(0);
+        pin_stage();
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if (PROF) { asm volatile("" ::"v"(x)); stamp(2); }  // phase 2: slice gather
       // two candidates per lane: the state itself (self-loop) and the inline target.  Both filter atomics are issued
       // by every lane, back to back, with one wait: a lane without a candidate ORs 0 (a no-op) into the word its
@@ -1012,7 +1063,8 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       const uint32_t t1 = (x & T1_MASK) | (e_keep & ~T1_MASK);  // v_bfi: a live e has only its slot bits outside the mask
       const uint32_t h0 = e & HMASK, h1 = x & HMASK;
       const uint32_t v0 = (x & RXE_SELF) ? 1u << (h0 & 31u) : 0u;    // bit to set, 0 = no candidate
-      const uint32_t v1 = (x & RXE_INLINE) ? 1u << (h1 & 31u) : 0u;
+      // (FOLD: a target that IS the folded state is dropped — the stream holds it anyway)
+      const uint32_t v1 = (FOLD ? (x & (RXE_INLINE | RXE_PIN)) == RXE_INLINE : (x & RXE_INLINE) != 0u) ? 1u << (h1 & 31u) : 0u;
       const uint32_t o0 = atomicOr(&sreg[fnext_off + (h0 >> 5)], v0);
       const uint32_t o1 = atomicOr(&sreg[fnext_off + (h1 >> 5)], v1);
       __builtin_amdgcn_sched_barrier(0);  // keep the first result's consumers behind the second atomic's issue
@@ -1053,14 +1105,14 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
         if (wballot(mycnt == 1u)) {
           const bool one = mycnt == 1u;
           const uint32_t w1 = one ? ovf[myoff + 1u] : 0u;
-          insert(one, (w1 & (RXE_TGT_MASK | RXE_ACCEPT)) | (sid << SID_SHIFT) | (STATS ? MARK : 0u), sreg);
+          insert(one && !(FOLD && (w1 & RXE_PIN)), (w1 & (RXE_TGT_MASK | RXE_ACCEPT)) | (sid << SID_SHIFT) | (STATS ? MARK : 0u), sreg);
         }
         mo = wballot(mycnt >= 2u);
         uint32_t total = 0, my_at = 0, my_sid = 0;
         auto flush = [&]() {
           const bool act = lane < total;
           const uint32_t w = act ? ovf[my_at] : 0u;
-          insert(act, (w & (RXE_TGT_MASK | RXE_ACCEPT)) | (my_sid << SID_SHIFT) | (STATS ? MARK : 0u), sreg0 + my_sid * L::STRIDE);
+          insert(act && !(FOLD && (w & RXE_PIN)), (w & (RXE_TGT_MASK | RXE_ACCEPT)) | (my_sid << SID_SHIFT) | (STATS ? MARK : 0u), sreg0 + my_sid * L::STRIDE);
           total = 0;
         };
         while (mo) {
@@ -1075,7 +1127,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
             for (uint32_t q0 = 0; q0 < cnt; q0 += 64u) {
               const bool act = q0 + lane < cnt;
               const uint32_t w = act ? ovf[off + 1u + q0 + lane] : 0u;
-              insert(act, (w & (RXE_TGT_MASK | RXE_ACCEPT)) | (osid << SID_SHIFT) | (STATS ? MARK : 0u), oreg);
+              insert(act && !(FOLD && (w & RXE_PIN)), (w & (RXE_TGT_MASK | RXE_ACCEPT)) | (osid << SID_SHIFT) | (STATS ? MARK : 0u), oreg);
             }
           } else {
             const uint32_t d = lane - total;  // lanes [total, total+cnt) take this entry's targets
@@ -1087,6 +1139,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
       }
     }
 
+    if (FOLD && !pin_done) pin_stage();  // no list entry this pass: the folded state is all there is
     stamp(5);  // phase 5: overflow lists + loop control
     if (consume) {
       if (__builtin_expect(Nn > L::CAPW, 0)) {
@@ -1105,13 +1158,14 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
             p.anymatch[(size_t)(stream0 + lane) * p.anymatch_stride + (k >> 5)] = sreg0[lane * L::STRIDE + 2u * L::FW + L::WINW];
           uint32_t* row = p.spill_rows + (size_t)slot * p.nw64x2;
           for (uint32_t w = 0; w < p.nw64x2; w++) row[w] = 0u;
+          if (FOLD && k >= 1u) row[p.pin_state >> 5] = 1u << (p.pin_state & 31u);  // S_k holds the folded state
         }
         __threadfence();
         wave_sync();
         for (uint32_t li = lane; li < N; li += 64u) {
           const uint32_t e = clist[li];
           const uint32_t sq = e & RXE_TGT_MASK;
-          uint32_t* row = p.spill_rows + (size_t)slotw[(e >> SID_SHIFT) & 31u] * p.nw64x2;
+          uint32_t* row = p.spill_rows + (size_t)slotw[(e >> SID_SHIFT) & SID_BITS] * p.nw64x2;
           atomicOr(&row[sq >> 5], 1u << (sq & 31u));
         }
         spilled = true;
@@ -1139,7 +1193,7 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
         k++;
       } while (k < k32 && !spilled);
       if (!spilled && p.anymatch && (k & 31u) == 0u) store_anymatch((k >> 5) - 1u);
-      if (PRUNE && (k & 63u) == 32u) stash_next_first();
+      if (LOOK && (k & 63u) == 32u) stash_next_first();
     }
   }
   while (k < p.n_passes && !spilled) {  // RX_MODE_FULL: pass N
@@ -1150,14 +1204,17 @@ __global__ void __launch_bounds__(256) rx_sym_pack_kernel(const RxParams p) {
   if (!spilled && p.anymatch && (k & 31u) != 0u) store_anymatch(k >> 5);
   if (PROF && lane == 0)
     for (int q = 0; q < 7; q++) atomicAdd(&p.counters[8 + q], t_sum[q]);
+  if (FOLD && lane == 0 && fold_entries) atomicAdd(&p.counters[7], fold_entries);
   // final active sets: rows were zeroed by the host-side memset; set the listed bits
   if (p.final_active && !spilled) {
     for (uint32_t li = lane; li < N; li += 64u) {
       const uint32_t e = clist[li];
       const uint32_t sq = e & RXE_TGT_MASK;
-      uint32_t* row = p.final_active + (size_t)(stream0 + ((e >> SID_SHIFT) & 31u)) * p.nw64x2;
+      uint32_t* row = p.final_active + (size_t)(stream0 + ((e >> SID_SHIFT) & SID_BITS)) * p.nw64x2;
       atomicOr(&row[sq >> 5], 1u << (sq & 31u));
     }
+    if (FOLD && owner && n_consume >= 1u)  // the folded state is in every set after the first byte
+      atomicOr(&p.final_active[(size_t)(stream0 + lane) * p.nw64x2 + (p.pin_state >> 5)], 1u << (p.pin_state & 31u));
   }
   if (STATS) {
     if (st_active) atomicAdd(&p.counters[1], st_active);
@@ -1449,6 +1506,158 @@ __global__ void __launch_bounds__(256) rx_dfa_kernel(const RxParams p) {
   }
 }
 
+// =================================================================================================
+// Kernel 6: register-resident active set, one wavefront per stream (few long streams)
+// =================================================================================================
+// The reference's own run is ONE lock-step pair of streams (testbench_BLK_Mem.sv:49-87): a single dependency chain
+// per stream, so what counts is the latency of a pass.  Here the active set never leaves the registers: lane L holds
+// at most one (state | accept flag) in a VGPR, EMPTY otherwise, and a pass is
+//     class of the byte (scalar, from a register window)  ->  ONE slice gather  ->  in-place update:
+//       the state stays (self loop)                         -> the lane keeps it,
+//       it moves on (one target, nothing else can reach it) -> the lane takes the target,
+//       it dies                                             -> the lane is free;
+//   no LDS list, no filter, no atomics.  What needs a lane of its own — a target next to a surviving state, a target
+//   that a second active state could also reach (RXE_MAYDUP: checked against all lanes with one compare), the targets
+//   of multi-target rows, what the folded `.*` state emits — goes through a short scalar loop (v_readlane, first free
+//   lane, v_writelane); on the shipped traces that is about one per pass.
+// FOLD as in the pack kernel (table in LDS, one uniform read per pass).  More than 64 active states: the stream is
+// handed to the wave kernel (resume mode) like in the group / pack kernels.
+template <bool FOLD>
+__global__ void __launch_bounds__(64) rx_sym_reg_kernel(const RxParams p) {
+  constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t* cmapw = lds;
+  const uint8_t* cmap = reinterpret_cast<const uint8_t*>(cmapw);
+  const uint32_t* pintab = lds + 64u;
+  const uint32_t pin_words = FOLD ? p.n_classes * p.pin_cols : 0u;
+  for (uint32_t w = lane; w < 64u; w += 64u) cmapw[w] = p.byte_class[w];
+  for (uint32_t w = lane; w < pin_words; w += 64u) lds[64u + w] = p.pin_tab[w];
+  wave_sync();
+  const uint32_t stream = blockIdx.x;
+  if (stream >= p.n_streams) return;
+  const uint32_t ncls = p.n_classes;
+  const uint32_t* __restrict__ symidx = p.symidx_c;
+  const uint32_t* __restrict__ ovf = p.ovf;
+  ByteFeed feed;
+  feed.base = p.bytes + (size_t)stream * p.stride;
+  feed.len = p.stream_len;
+  feed.aligned = ((reinterpret_cast<uintptr_t>(feed.base)) & 3u) == 0;
+  auto classes = [&](uint32_t v) {
+    return (uint32_t)cmap[v & 0xFFu] | ((uint32_t)cmap[(v >> 8) & 0xFFu] << 8) | ((uint32_t)cmap[(v >> 16) & 0xFFu] << 16) |
+           ((uint32_t)cmap[v >> 24] << 24);
+  };
+  uint32_t cw = 0, nxt = feed.load_chunk(0, lane);  // classes of this lane's 4 bytes of the current 256-byte chunk; next chunk, raw
+  uint32_t e = lane == 0 ? p.state0_entry : EMPTY;    // FPGA.v:134-147: current = {state 0}
+  uint32_t am_word = 0;
+  const uint32_t n_consume = p.n_consume < p.n_passes ? p.n_consume : p.n_passes;
+  bool handed_off = false;
+  // shader clock the stream ran at (diagnostic; read by RX_OPT_VERBOSE): cycles and 100 MHz ticks of stream 0
+  const unsigned long long t0c = __builtin_amdgcn_s_memtime(), t0r = __builtin_amdgcn_s_memrealtime();
+
+  for (uint32_t k = 0; k < p.n_passes; k++) {
+    // accept pulses of S_k (FPGA.v:210-226)
+    {
+      const bool acc = (e & (0x80000000u | RXE_ACCEPT)) == RXE_ACCEPT;  // EMPTY has bit 31 set
+      if (wballot(acc)) emit_events(p, acc, e & RXE_TGT_MASK, stream, k, lane, am_word);
+    }
+    if (k < n_consume) {
+      if ((k & 255u) == 0u) {
+        cw = classes(nxt);
+        nxt = feed.load_chunk((k >> 8) + 1u, lane);  // one chunk ahead
+      }
+      const uint32_t c = (bcast(cw, (k >> 2) & 63u) >> ((k & 3u) * 8u)) & 0xFFu;  // class of input_char
+      const uint32_t e_in = e;
+      const bool live = (e & (0x80000000u | RXE_ACCEPT)) == 0u;
+      uint32_t x = 0u;
+      if (live) x = symidx[__umul24(e & RXE_TGT_MASK, ncls) + c];  // the current byte's slice of that state's row
+      uint32_t vA = 0u;
+      if (FOLD && k >= 1u) {  // what the folded `.*` state emits, reduced to the targets that survive the next byte
+        uint32_t sel = ncls;
+        if (k + 1u < n_consume) {
+          const uint32_t k1 = k + 1u;
+          sel = (k1 & 255u) ? (bcast(cw, (k1 >> 2) & 63u) >> ((k1 & 3u) * 8u)) & 0xFFu
+                            : (uint32_t)__builtin_amdgcn_readfirstlane((int)cmap[bcast(nxt, 0) & 0xFFu]);
+        }
+        vA = pintab[c * p.pin_cols + sel];  // same address in every lane: one broadcast read
+      }
+      const bool surv = (x & RXE_SELF) != 0u;
+      const bool inl = FOLD ? (x & (RXE_INLINE | RXE_PIN)) == RXE_INLINE : (x & RXE_INLINE) != 0u;
+      const bool own = inl && !surv && !(x & RXE_MAYDUP);  // moves on, nothing else can reach the target: in place
+      e = surv ? e : (own ? (x & (RXE_TGT_MASK | RXE_ACCEPT)) : EMPTY);
+      uint64_t mx = wballot(inl && !own);  // targets that need a lane of their own / a duplicate check
+      uint64_t mo = wballot(x & RXE_OVF);
+      if (__builtin_expect((mx | mo) != 0ull || vA != 0u, 0)) {
+        uint64_t mfree = wballot(e == EMPTY);
+        bool full = false;
+        auto place = [&](uint32_t tw) {  // tw wave-uniform: target | RXE_ACCEPT | RXE_MAYDUP | RXE_PIN
+          if (FOLD && (tw & RXE_PIN)) return;
+          if ((tw & RXE_MAYDUP) && wballot(((e ^ tw) & RXE_TGT_MASK) == 0u)) return;  // already in the next set
+          if (mfree == 0ull) { full = true; return; }
+          const uint32_t dst = (uint32_t)__builtin_ctzll(mfree);
+          mfree &= mfree - 1ull;
+          if (lane == dst) e = tw & (RXE_TGT_MASK | RXE_ACCEPT);
+        };
+        auto place_list = [&](uint32_t off) {
+          const uint32_t cnt = ovf[off];
+          for (uint32_t j0 = 0; j0 < cnt; j0 += 64u) {
+            const uint32_t mine = j0 + lane < cnt ? ovf[off + 1u + j0 + lane] : 0u;  // one coalesced load per 64 targets
+            const uint32_t lim = cnt - j0 < 64u ? cnt - j0 : 64u;
+            for (uint32_t j = 0; j < lim; j++) place(bcast(mine, j));
+          }
+        };
+        while (mx) {
+          const uint32_t src = (uint32_t)__builtin_ctzll(mx);
+          mx &= mx - 1ull;
+          place(bcast(x, src));
+        }
+        while (mo) {
+          const uint32_t src = (uint32_t)__builtin_ctzll(mo);
+          mo &= mo - 1ull;
+          place_list(bcast(x, src) & RXE_TGT_MASK);
+        }
+        if (FOLD) {
+          if (vA & RXE_INLINE) place(vA);
+          else if (vA & RXE_OVF) place_list(vA & RXE_TGT_MASK);
+        }
+        if (__builtin_expect(full, 0)) {
+          // more than 64 active states: hand the stream (S_k, k) to the wave kernel
+          unsigned long long b = 0;
+          if (lane == 0) b = atomicAdd(p.spill_count, 1ull);
+          const uint32_t slot = bcast((uint32_t)b, 0);
+          uint32_t* row = p.spill_rows + (size_t)slot * p.nw64x2;
+          for (uint32_t w = lane; w < p.nw64x2; w += 64u) row[w] = 0u;
+          if (lane == 0) {
+            p.spill_streams[slot] = stream;
+            p.spill_k[slot] = k;
+            if (p.anymatch) p.anymatch[(size_t)stream * p.anymatch_stride + (k >> 5)] = am_word;
+          }
+          __threadfence();
+          wave_sync();
+          if (e_in != EMPTY) atomicOr(&row[(e_in & RXE_TGT_MASK) >> 5], 1u << (e_in & 31u));
+          if (FOLD && k >= 1u && lane == 0) atomicOr(&row[p.pin_state >> 5], 1u << (p.pin_state & 31u));
+          handed_off = true;
+          break;
+        }
+      }
+    }
+    if (p.anymatch && ((k & 31u) == 31u || k + 1 == p.n_passes)) {
+      if (lane == 0) p.anymatch[(size_t)stream * p.anymatch_stride + (k >> 5)] = am_word;
+      am_word = 0;
+    }
+  }
+  if (stream == 0 && lane == 0) {
+    p.counters[8] = __builtin_amdgcn_s_memtime() - t0c;
+    p.counters[9] = __builtin_amdgcn_s_memrealtime() - t0r;
+  }
+  // final active set: the row was zeroed by the host-side memset
+  if (p.final_active && !handed_off) {
+    uint32_t* row = p.final_active + (size_t)stream * p.nw64x2;
+    if (e != EMPTY) atomicOr(&row[(e & RXE_TGT_MASK) >> 5], 1u << (e & 31u));
+    if (FOLD && n_consume >= 1u && lane == 0) atomicOr(&row[p.pin_state >> 5], 1u << (p.pin_state & 31u));
+  }
+}
+
 }  // namespace
 
 // -------------------------------------------------------------------------------------------------
@@ -1457,9 +1666,10 @@ __global__ void __launch_bounds__(256) rx_dfa_kernel(const RxParams p) {
 int rx_pick_launch(uint32_t kernel, uint32_t size, uint32_t n_streams, int cu_count, size_t lds_per_cu,
                    RxParams* p, RxLaunchCfg* cfg) {
   cfg->cu_count = cu_count;
+  cfg->lds_per_cu = lds_per_cu;
   if (kernel == RX_KERNEL_AUTO) kernel = RX_KERNEL_SYM_PACK;  // fastest parity-checked kernel
   if (kernel != RX_KERNEL_CSR_WAVE && kernel != RX_KERNEL_SYM_WAVE && kernel != RX_KERNEL_SYM_GROUP &&
-      kernel != RX_KERNEL_SYM_PACK && kernel != RX_KERNEL_DFA)
+      kernel != RX_KERNEL_SYM_PACK && kernel != RX_KERNEL_DFA && kernel != RX_KERNEL_SYM_REG)
     return RX_EINVAL;
   const uint32_t nw32 = (size + 31u) / 32u;
   p->nw32 = nw32;
@@ -1477,7 +1687,7 @@ int rx_pick_launch(uint32_t kernel, uint32_t size, uint32_t n_streams, int cu_co
   if (kernel == RX_KERNEL_SYM_PACK) {
     const uint32_t gl = cfg->group_lanes;  // here: streams per wavefront
     if (gl != 2 && gl != 4 && gl != 8 && gl != 11 && gl != 12 && gl != 13 && gl != 16 && gl != 20 && gl != 22 && gl != 24 &&
-        gl != 32)
+        gl != 32 && gl != 48 && gl != 64)  // 48 and 64 exist as FOLD builds only (rx_launch maps them down otherwise)
       cfg->group_lanes = 16;
   }
   if (kernel == RX_KERNEL_SYM_GROUP) {
@@ -1518,23 +1728,49 @@ static int launch_group(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s
 
 template <int S, bool PRUNE>
 static int launch_pack_as(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s) {
-  using L = PackLayout<S, PRUNE>;
+  using L = PackLayout<S, PRUNE, false>;
   const uint32_t wpb = 4;
   const uint32_t waves = (p.n_streams + S - 1) / S;
   const uint32_t grid = (waves + wpb - 1) / wpb;
   const uint32_t g = grid ? grid : 1;
   const uint32_t lds = (L::CMAPW + wpb * L::WAVE_WORDS) * 4u;
-  if (PRUNE) return launch_one(rx_sym_pack_kernel<S, false, false, true>, p, g, wpb * 64u, lds, s);
-  if (cfg.stats) return launch_one(rx_sym_pack_kernel<S, true, false, false>, p, g, wpb * 64u, lds, s);
+  if (PRUNE) return launch_one(rx_sym_pack_kernel<S, false, false, true, false>, p, g, wpb * 64u, lds, s);
+  if (cfg.stats) return launch_one(rx_sym_pack_kernel<S, true, false, false, false>, p, g, wpb * 64u, lds, s);
   if (S == 16 && cfg.profile_pack)  // stamped diagnostic build, see the kernel's PROF note
-    return launch_one(rx_sym_pack_kernel<16, false, true, false>, p, g, wpb * 64u, lds, s);
-  return launch_one(rx_sym_pack_kernel<S, false, false, false>, p, g, wpb * 64u, lds, s);
+    return launch_one(rx_sym_pack_kernel<16, false, true, false, false>, p, g, wpb * 64u, lds, s);
+  return launch_one(rx_sym_pack_kernel<S, false, false, false, false>, p, g, wpb * 64u, lds, s);
 }
 
 template <int S>
 static int launch_pack(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s) {
   if (cfg.prune && !cfg.stats && p.ovf_dir) return launch_pack_as<S, true>(p, cfg, s);
   return launch_pack_as<S, false>(p, cfg, s);
+}
+
+// FOLD builds: the block shares one copy of the folding table, so blocks are as large as the LDS allows (up to 8
+// wavefronts); never with statistics.
+template <int S>
+static int launch_fold(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s, size_t lds_per_cu) {
+  const bool prune = cfg.prune && p.ovf_dir;
+  const uint32_t ww = prune ? PackLayout<S, true, true>::WAVE_WORDS : PackLayout<S, false, true>::WAVE_WORDS;
+  const uint32_t fixed = PackLayout<S, false, true>::CMAPW + p.n_classes * p.pin_cols;
+  const uint32_t waves = (p.n_streams + S - 1) / S;
+  // wavefronts per block: the one that keeps the most wavefronts resident per CU (every block carries its own copy of
+  // the folding table), ties to the smaller block; enough blocks to reach every CU
+  uint32_t wpb = 0, best = 0;
+  for (uint32_t w = 1; w <= 8; w++) {
+    const size_t bytes = (size_t)(fixed + w * ww) * 4u;
+    if (bytes > lds_per_cu) break;
+    const uint32_t blocks = (uint32_t)std::min<size_t>(lds_per_cu / bytes, 32u / w);
+    const uint32_t resident = blocks * w;
+    if (resident > best && (w == 1 || (waves + w - 1) / w >= 256u)) { best = resident; wpb = w; }
+  }
+  if (wpb == 0) return (int)hipErrorInvalidValue;
+  const uint32_t grid = (waves + wpb - 1) / wpb;
+  const uint32_t g = grid ? grid : 1;
+  const uint32_t lds = (fixed + wpb * ww) * 4u;
+  if (prune) return launch_one(rx_sym_pack_kernel<S, false, false, true, true>, p, g, wpb * 64u, lds, s);
+  return launch_one(rx_sym_pack_kernel<S, false, false, false, true>, p, g, wpb * 64u, lds, s);
 }
 
 // returns a hipError_t value (0 = hipSuccess)
@@ -1549,15 +1785,31 @@ int rx_launch(const RxParams& p, const RxLaunchCfg& cfg, void* hip_stream) {
       return cfg.stats ? launch_one(rx_sym_wave_kernel<true>, p, cfg.grid_blocks, cfg.block_threads, cfg.lds_bytes, s)
                        : launch_one(rx_sym_wave_kernel<false>, p, cfg.grid_blocks, cfg.block_threads, cfg.lds_bytes, s);
     case RX_KERNEL_DFA:
+    case RX_KERNEL_SYM_REG:
     case RX_KERNEL_SYM_PACK:
     case RX_KERNEL_SYM_GROUP: {
       int e;
-      if (cfg.kernel == RX_KERNEL_DFA) {
+      if (cfg.kernel == RX_KERNEL_SYM_REG) {  // one wavefront (= one block) per stream
+        const bool fold = cfg.fold && p.pin_tab;
+        const uint32_t lds = (64u + (fold ? p.n_classes * p.pin_cols : 0u)) * 4u;
+        e = fold ? launch_one(rx_sym_reg_kernel<true>, p, p.n_streams, 64u, lds, s)
+                 : launch_one(rx_sym_reg_kernel<false>, p, p.n_streams, 64u, lds, s);
+      } else if (cfg.kernel == RX_KERNEL_DFA) {
         const uint32_t wpb = 4;
         const uint32_t grid = (p.n_streams + wpb * 64u - 1) / (wpb * 64u);
         const uint32_t lds = (64u + wpb * (p.nw32 + 64u)) * 4u;
         e = cfg.stats ? launch_one(rx_dfa_kernel<true>, p, grid ? grid : 1, wpb * 64u, lds, s)
                       : launch_one(rx_dfa_kernel<false>, p, grid ? grid : 1, wpb * 64u, lds, s);
+      } else if (cfg.kernel == RX_KERNEL_SYM_PACK && cfg.fold && !cfg.stats && p.pin_tab) {
+        const size_t lds_cu = cfg.lds_per_cu ? cfg.lds_per_cu : 160u * 1024u;
+        const uint32_t gl = cfg.group_lanes;  // nearest instantiated number of streams per wavefront
+        if (gl <= 8) e = launch_fold<8>(p, cfg, s, lds_cu);
+        else if (gl <= 13) e = launch_fold<13>(p, cfg, s, lds_cu);
+        else if (gl <= 16) e = launch_fold<16>(p, cfg, s, lds_cu);
+        else if (gl <= 24) e = launch_fold<24>(p, cfg, s, lds_cu);
+        else if (gl <= 32) e = launch_fold<32>(p, cfg, s, lds_cu);
+        else if (gl <= 48) e = launch_fold<48>(p, cfg, s, lds_cu);
+        else e = launch_fold<64>(p, cfg, s, lds_cu);
       } else if (cfg.kernel == RX_KERNEL_SYM_PACK) {
         if (cfg.group_lanes == 2) e = launch_pack<2>(p, cfg, s);
         else if (cfg.group_lanes == 4) e = launch_pack<4>(p, cfg, s);
@@ -1568,7 +1820,7 @@ int rx_launch(const RxParams& p, const RxLaunchCfg& cfg, void* hip_stream) {
         else if (cfg.group_lanes == 22) e = launch_pack<22>(p, cfg, s);
         else if (cfg.group_lanes == 20) e = launch_pack<20>(p, cfg, s);
         else if (cfg.group_lanes == 24) e = launch_pack<24>(p, cfg, s);
-        else if (cfg.group_lanes == 32) e = launch_pack<32>(p, cfg, s);
+        else if (cfg.group_lanes >= 32) e = launch_pack<32>(p, cfg, s);
         else e = launch_pack<16>(p, cfg, s);
       } else if (cfg.group_lanes == 1) e = launch_group<1>(p, cfg, s);
       else if (cfg.group_lanes == 2) e = launch_group<2>(p, cfg, s);

@@ -24,7 +24,16 @@ def kernels(rx):
             dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=16), dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=4),
             dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=8), dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=13),
             dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=16), dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=24),
-            dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=32), dict(kernel=rx.KERNEL_DFA), dict(kernel=rx.KERNEL_AUTO)]
+            dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=32), dict(kernel=rx.KERNEL_DFA), dict(kernel=rx.KERNEL_AUTO),
+            # FOLD builds (always-on-state folding; plain pack kernel on automata without such a state)
+            dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=8, flags=rx.host.OPT_FORCE_FOLD),
+            dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=16, flags=rx.host.OPT_FORCE_FOLD | rx.host.OPT_FORCE_PRUNE),
+            dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=24, flags=rx.host.OPT_FORCE_FOLD),
+            dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=32, flags=rx.host.OPT_FORCE_FOLD),
+            dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=48, flags=rx.host.OPT_FORCE_FOLD | rx.host.OPT_FORCE_PRUNE),
+            dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=64, flags=rx.host.OPT_FORCE_FOLD),
+            # register-resident one-wavefront-per-stream kernel, folded (default) and unfolded
+            dict(kernel=rx.KERNEL_SYM_REG), dict(kernel=rx.KERNEL_SYM_REG, flags=rx.host.OPT_NO_FOLD)]
 
 
 @pytest.fixture(scope="module")
