@@ -72,6 +72,7 @@ struct DevTables {
   uint32_t* symidx_c = nullptr;
   uint32_t *symidx_p = nullptr, *ovf_dir = nullptr;  // look-ahead pruning tables (pack kernel), may stay null
   uint32_t* pin_tab = nullptr;                       // folding table of the pinned state (pack kernel), may stay null
+  uint32_t* regidx = nullptr;                        // register kernel's index, may stay null (huge automata)
   uint32_t* byte_class = nullptr;
   // lazy-DFA cache (allocated by the first RX_KERNEL_DFA launch)
   uint32_t *dfa_trans = nullptr, *dfa_pool = nullptr, *dfa_hash = nullptr, *dfa_hdr = nullptr;
@@ -176,6 +177,7 @@ extern "C" void rx_nfa_free(rx_nfa* nfa) {
     (void)hipFree(kv.second.symidx_p);
     (void)hipFree(kv.second.ovf_dir);
     (void)hipFree(kv.second.pin_tab);
+    (void)hipFree(kv.second.regidx);
     (void)hipFree(kv.second.byte_class);
     (void)hipFree(kv.second.dfa_trans);
     (void)hipFree(kv.second.dfa_pool);
@@ -254,6 +256,7 @@ static int get_dev_tables(const rx_nfa* cnfa, int device, DevTables* out) {
     if ((rc = upload_vec(nfa->h.ovf_dir, &t.ovf_dir))) return rc;
   }
   if (!nfa->h.pin_tab.empty() && (rc = upload_vec(nfa->h.pin_tab, &t.pin_tab))) return rc;
+  if (!nfa->h.regidx.empty() && (rc = upload_vec(nfa->h.regidx, &t.regidx))) return rc;
   {
     std::vector<uint32_t> bc(64);
     memcpy(bc.data(), nfa->h.byte_class, 256);
@@ -353,7 +356,12 @@ struct rx_plan {
   size_t d_in_own_bytes = 0;
   const uint8_t* d_in = nullptr;
   rx_event* d_events = nullptr;
-  unsigned long long* d_counters = nullptr;
+  // two sets of {counters[16], match_count_total[size]} that alternate between launches: the kernel zeroes the set of
+  // the NEXT launch (RxParams::zero_next), so no reset has to be enqueued between two launches
+  unsigned long long* d_cset[2] = {nullptr, nullptr};
+  int cur_set = 0;             // the set the LAST launch used (what download reads)
+  bool sets_clean = false;     // both sets are zero except for what the last launch accumulated in d_cset[cur_set]
+  unsigned long long* d_counters = nullptr;  // == d_cset[cur_set]
   uint32_t* d_mc = nullptr;
   unsigned long long* d_mct = nullptr;
   uint32_t* d_am = nullptr;
@@ -444,9 +452,14 @@ extern "C" int rx_plan_create(const rx_nfa* nfa, const rx_opts* opts, size_t max
   const size_t nw64x2 = 2 * (((size_t)size + 63) / 64);
   auto fail = [&](int code) { rx_plan_free(p); return code; };
 #define PLCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(hip_fail(e_, #call)); } while (0)
-  PLCHK(hipMalloc((void**)&p->d_counters, 16 * sizeof(unsigned long long)));
+  for (int q = 0; q < 2; q++) {
+    PLCHK(hipMalloc((void**)&p->d_cset[q], (16 + (size_t)size) * sizeof(unsigned long long)));
+    PLCHK(hipMemset(p->d_cset[q], 0, (16 + (size_t)size) * sizeof(unsigned long long)));
+  }
+  p->d_counters = p->d_cset[0];
+  p->d_mct = p->d_cset[0] + 16;
+  p->sets_clean = true;
   PLCHK(hipMalloc((void**)&p->d_events, std::max<size_t>(events_cap, 1) * sizeof(rx_event)));
-  PLCHK(hipMalloc((void**)&p->d_mct, (size_t)size * sizeof(unsigned long long)));
   if (p->want_mc) PLCHK(hipMalloc((void**)&p->d_mc, max_streams * size * sizeof(uint32_t)));
   p->am_stride = (size_t)((passes_for(max_stream_len, RX_MODE_FULL) + 31) / 32);
   if (p->want_am) PLCHK(hipMalloc((void**)&p->d_am, max_streams * p->am_stride * sizeof(uint32_t)));
@@ -464,9 +477,9 @@ extern "C" void rx_plan_free(rx_plan* p) {
   (void)hipSetDevice(p->device);
   (void)hipFree(p->d_in_own);
   (void)hipFree(p->d_events);
-  (void)hipFree(p->d_counters);
+  (void)hipFree(p->d_cset[0]);
+  (void)hipFree(p->d_cset[1]);
   (void)hipFree(p->d_mc);
-  (void)hipFree(p->d_mct);
   (void)hipFree(p->d_am);
   (void)hipFree(p->d_final);
   (void)hipFree(p->d_init);
@@ -586,6 +599,7 @@ static void fill_common(rx_plan* p, RxParams& a) {
   a.ovf_dir = p->tab.ovf_dir;
   a.byte_class = p->tab.byte_class;
   a.pin_tab = p->tab.pin_tab;
+  a.regidx = p->tab.regidx;
   a.pin_cols = h.n_classes + 1u;
   a.n_classes = h.n_classes;
   a.size = h.size;
@@ -642,6 +656,7 @@ static int auto_probe(rx_plan* p) {
     cfg.fold = run_fold && !stats;
     if ((rc = ensure_spill_area(p, a))) return rc;
     HIPCHK(hipMemsetAsync(p->d_counters, 0, 16 * sizeof(unsigned long long), p->stream));
+    p->sets_clean = false;  // (the probe accumulates into the current set; both are reset before the real launch)
     hipError_t e = (hipError_t)rx_launch(a, cfg, p->stream);
     if (e != hipSuccess) return hip_fail(e, "probe launch");
     HIPCHK(hipMemcpyAsync(cnt, p->d_counters, sizeof(cnt), hipMemcpyDeviceToHost, p->stream));
@@ -762,7 +777,8 @@ extern "C" int rx_plan_launch(rx_plan* p) {
   a.pair_cycles = pair ? 1u : 0u;
   // few long streams from reset (the reference's own run is one lock-step pair): latency per pass is what counts, and the
   // register-resident kernel has the shortest pass; it has no statistics build
-  if (kernel == RX_KERNEL_AUTO && p->n_streams <= 4 && p->opts.collect_stats == 0 && !p->have_init) kernel = RX_KERNEL_SYM_REG;
+  if (kernel == RX_KERNEL_AUTO && p->n_streams <= 4 && p->opts.collect_stats == 0 && !p->have_init && p->tab.regidx)
+    kernel = RX_KERNEL_SYM_REG;
   // the probe also serves an explicit RX_KERNEL_SYM_PACK: whether look-ahead pruning pays depends on the input
   const bool probe_for_pack = kernel == RX_KERNEL_SYM_PACK && p->tab.ovf_dir && p->opts.collect_stats == 0;
   if ((kernel == RX_KERNEL_AUTO || probe_for_pack) && !pair && !p->have_init) {
@@ -782,7 +798,7 @@ extern "C" int rx_plan_launch(rx_plan* p) {
   if (p->have_init && (kernel == RX_KERNEL_AUTO || kernel == RX_KERNEL_SYM_GROUP || kernel == RX_KERNEL_SYM_PACK ||
                        kernel == RX_KERNEL_DFA || kernel == RX_KERNEL_SYM_REG))
     kernel = RX_KERNEL_SYM_WAVE;
-  if (kernel == RX_KERNEL_SYM_REG && p->opts.collect_stats != 0) kernel = RX_KERNEL_SYM_WAVE;
+  if (kernel == RX_KERNEL_SYM_REG && (p->opts.collect_stats != 0 || !p->tab.regidx)) kernel = RX_KERNEL_SYM_WAVE;
   p->cfg.group_lanes = auto_lanes ? auto_lanes : p->opts.group_lanes;
   rc = rx_pick_launch(kernel, h.size, a.n_streams, p->tab.cu_count, p->tab.lds_per_cu, &a, &p->cfg);
   if (rc) return rc;
@@ -793,6 +809,7 @@ extern "C" int rx_plan_launch(rx_plan* p) {
                 ((p->cfg.kernel == RX_KERNEL_SYM_PACK &&
                   ((p->opts.flags & RX_OPT_FORCE_FOLD) != 0 || (p->opts.kernel == RX_KERNEL_AUTO && p->auto_fold))) ||
                  p->cfg.kernel == RX_KERNEL_SYM_REG);  // the register kernel folds whenever the automaton allows
+  if (p->cfg.kernel == RX_KERNEL_SYM_REG) p->cfg.fold = p->tab.pin_tab != nullptr;  // (its index is built for exactly that)
   if (p->cfg.fold && p->cfg.kernel == RX_KERNEL_SYM_PACK) {
     static const uint32_t fold_s[] = {8, 13, 16, 24, 32, 48, 64};
     uint32_t pick = 64;
@@ -824,8 +841,21 @@ extern "C" int rx_plan_launch(rx_plan* p) {
     a.dfa_hash_mask = t.dfa_hash_mask;
   }
 
-  HIPCHK(hipMemsetAsync(p->d_counters, 0, 16 * sizeof(unsigned long long), p->stream));
-  HIPCHK(hipMemsetAsync(p->d_mct, 0, (size_t)h.size * sizeof(unsigned long long), p->stream));
+  // counters + match_count_total: the other set, which the previous launch's kernel has zeroed (or, after a probe or
+  // the plan's creation, a reset enqueued here); this launch's kernel zeroes the one after
+  const size_t set_words = 16 + (size_t)h.size;
+  if (!p->sets_clean) {
+    for (int q = 0; q < 2; q++) HIPCHK(hipMemsetAsync(p->d_cset[q], 0, set_words * sizeof(unsigned long long), p->stream));
+    p->sets_clean = true;
+  }
+  p->cur_set ^= 1;
+  p->d_counters = p->d_cset[p->cur_set];
+  p->d_mct = p->d_counters + 16;
+  a.counters = p->d_counters;
+  a.match_count_total = p->d_mct;
+  if (a.spill_count) a.spill_count = p->d_counters + 3;
+  a.zero_next = p->d_cset[p->cur_set ^ 1];
+  a.zero_words = (uint32_t)set_words;
   if (p->want_mc) HIPCHK(hipMemsetAsync(p->d_mc, 0, p->n_streams * h.size * sizeof(uint32_t), p->stream));
   if (p->n_timed >= 4096) p->n_timed = 0;  // nobody is reading the times: recycle the pool
   if (p->n_timed == p->evs.size()) {
@@ -836,8 +866,6 @@ extern "C" int rx_plan_launch(rx_plan* p) {
   }
   auto& ev = p->evs[p->n_timed];
   HIPCHK(hipEventRecord(ev.first, p->stream));  // brackets the match kernel(s) only, on their own stream
-  if (two_tier && p->want_final)  // the group / pack kernels OR bits into zeroed rows
-    HIPCHK(hipMemsetAsync(p->d_final, 0, p->n_streams * (size_t)a.nw64x2 * sizeof(uint32_t), p->stream));
   hipError_t e = (hipError_t)rx_launch(a, p->cfg, p->stream);
   if (e != hipSuccess) return hip_fail(e, "kernel launch");
   HIPCHK(hipEventRecord(ev.second, p->stream));

@@ -382,6 +382,8 @@ int rxh_build(const uint32_t* W, size_t nwords, uint32_t size_or_0, RxHostNfa* o
           }
         }
       }
+    // one all-zero row behind the per-class index: the id `size` is the register kernel's "free lane" (rx_kernels.hip)
+    out->symidx_c.resize((size_t)(size + 1u) * ncls, 0u);
     if (!out->pin_tab.empty())
       for (uint32_t k = 0; k < ncls; k++)
         for (uint32_t n = 0; n <= ncls; n++) {
@@ -389,6 +391,24 @@ int rxh_build(const uint32_t* W, size_t nwords, uint32_t size_or_0, RxHostNfa* o
           if ((w & RXE_INLINE) && dup(w & RXE_TGT_MASK, k)) w |= RXE_MAYDUP;
           if (w & RXE_OVF) flag_list(w & RXE_TGT_MASK, k);
         }
+    // ---- the register kernel's index: the in-place update of a lane precomputed per (state, class) ------------------
+    out->regidx.clear();
+    if ((uint64_t)(size + 1u) * ncls * 8u <= ((uint64_t)256 << 20)) {
+      const bool fold = !out->pin_tab.empty();
+      out->regidx.assign((size_t)(size + 1u) * ncls * 2u, 0u);
+      for (uint32_t i = 0; i <= size; i++)
+        for (uint32_t k = 0; k < ncls; k++) {
+          const uint32_t w = out->symidx_c[(size_t)i * ncls + k];  // (row `size` is all zero)
+          const bool surv = (w & RXE_SELF) != 0u;
+          const bool inl = (w & RXE_INLINE) != 0u && !(fold && (w & RXE_PIN));
+          const bool own = inl && !surv && !(w & RXE_MAYDUP);  // moves on to a target nothing else can reach: in place
+          uint32_t fast = surv ? i : (own ? (w & RXE_TGT_MASK) : size);
+          if (own && (w & RXE_ACCEPT)) fast |= RXR_ACC;
+          if ((inl && !own) || (w & RXE_OVF)) fast |= RXR_NEED;
+          out->regidx[((size_t)i * ncls + k) * 2u] = fast;
+          out->regidx[((size_t)i * ncls + k) * 2u + 1u] = w;
+        }
+    }
   }
   return RX_OK;
 }

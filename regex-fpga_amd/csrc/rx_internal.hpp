@@ -26,6 +26,8 @@ static constexpr uint32_t RXE_PIN = 0x08000000u;   // target is the pinned state
 // is inserted.  Per-class index, overflow lists and the folding table carry the flag; kernels that deduplicate every
 // insertion through a filter ignore it, the register-resident single-stream kernel checks only flagged targets.
 static constexpr uint32_t RXE_MAYDUP = 0x04000000u;
+static constexpr uint32_t RXR_NEED = 0x80000000u;  // register kernel's fast word (RxParams::regidx)
+static constexpr uint32_t RXR_ACC = 0x40000000u;
 static constexpr uint32_t RXE_TGT_MASK = 0x00FFFFFFu;
 
 // Active-list entry (LDS): state id in bits 23:0, RXE_ACCEPT if the state is an accept state.
@@ -53,6 +55,11 @@ struct RxParams {
   // foldable state.
   const uint32_t* pin_tab;
   uint32_t pin_cols;            // n_classes + 1
+  // register kernel's index: [(size + 1)][n_classes] pairs {fast word, slice word}.  Fast word: bits 23:0 = what the lane
+  // holds after the byte (the state itself if it loops, its one target if nothing else can reach that, else the id
+  // `size` = free), RXR_NEED = something needs a lane of its own (see rx_sym_reg_kernel), RXR_ACC = bits 23:0 name an
+  // accept state.  Row `size` is all {size, 0}.  Built with the folded state's targets dropped iff pin_tab exists.
+  const uint32_t* regidx;
   const uint32_t* byte_class;   // [64] words = 256 bytes: class id of every input byte
   uint32_t n_classes;
   const uint32_t* ovf;          // overflow target lists of the slice index
@@ -75,6 +82,11 @@ struct RxParams {
   uint32_t events_cap;
   unsigned long long* counters; // [0] n_events [1] sum_active [2] sum_edges [3] spilled streams [4] pair clock cost
                                 // pack statistics build: [5] entries on multi-target rows [6] of their targets, dead at once [7] its own active
+  // The plan keeps TWO sets of {counters[16], match_count_total[size]} and alternates between them: the kernel of launch
+  // n accumulates into one set and its first block zeroes the other for launch n+1, so that no reset sits between two
+  // launches on the stream.  Null / 0 for launches that must not do that (the resume launch, AUTO's probe).
+  unsigned long long* zero_next;
+  uint32_t zero_words;
   uint32_t* match_count;        // [n_streams][size] or null
   unsigned long long* match_count_total; // [size] or null
   uint32_t* anymatch;           // [n_streams][anymatch_stride] or null
@@ -148,6 +160,8 @@ struct RxHostNfa {
   // folding table of the pinned state (RxParams::pin_tab), n_classes * (n_classes + 1) words; empty unless state 0
   // enters the pinned state on every byte (then every stream that starts from reset holds it from pass 1 on)
   std::vector<uint32_t> pin_tab;
+  // RxParams::regidx; empty for automata whose table would exceed 256 MB (the register kernel is then not offered)
+  std::vector<uint32_t> regidx;
   const uint32_t* row_ptr() const { return words.data(); }
   const uint32_t* col() const { return words.data() + size + 1; }
 };

@@ -63,6 +63,21 @@ __device__ __forceinline__ uint32_t bcast(uint32_t v, uint32_t src_lane) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src_lane);
 }
 
+// ---- launch prologue: what used to be host-side resets between two launches ------------------------
+// Block 0 zeroes the counter set of the NEXT launch (RxParams::zero_next); nothing in this launch touches that set.
+__device__ __forceinline__ void zero_next_counters(const RxParams& p) {
+  if (blockIdx.x == 0 && p.zero_next)
+    for (uint32_t w = threadIdx.x; w < p.zero_words; w += blockDim.x) p.zero_next[w] = 0ull;
+}
+// Kernels that set bits in the final-set rows (instead of storing whole rows) first clear the rows of their own streams
+// [first, first + n); the same wavefront ORs the bits in much later, through the same L2.
+__device__ __forceinline__ void zero_final_rows(const RxParams& p, uint32_t first, uint32_t n, uint32_t lane) {
+  if (!p.final_active) return;
+  uint32_t* rows = p.final_active + (size_t)first * p.nw64x2;
+  const uint32_t words = n * p.nw64x2;
+  for (uint32_t w = lane; w < words; w += 64u) rows[w] = 0u;
+}
+
 // ---- input bytes: 256-byte chunks, one dword per lane ------------------------------------------
 struct ByteFeed {
   const uint8_t* base;
@@ -237,6 +252,7 @@ __global__ void __launch_bounds__(256) rx_csr_wave_kernel(const RxParams p) {
   const uint32_t* __restrict__ rp = p.words;                // row_ptr  (FPGA.v:780-786 addresses i>>2)
   const uint32_t* __restrict__ col = p.words + p.size + 1;  // offset = size+1 (FPGA.v:773,793)
   unsigned long long st_active = 0, st_edges = 0;
+  zero_next_counters(p);
 
   for (uint32_t stream = blockIdx.x * wpb + wib; stream < p.n_streams; stream += gridDim.x * wpb) {
     StreamState st;
@@ -328,6 +344,7 @@ __global__ void __launch_bounds__(256) rx_sym_wave_kernel(const RxParams p) {
   const uint32_t* __restrict__ symidx = p.symidx;
   const uint32_t* __restrict__ ovf = p.ovf;
   unsigned long long st_active = 0, st_edges = 0;
+  zero_next_counters(p);
   // resume mode: finish the streams the group kernel handed off (their active set outgrew its list)
   uint32_t total = p.n_streams;
   if (p.resume) {
@@ -469,9 +486,12 @@ __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
       pinrow[w] = symidx[(size_t)p.pin_state * 256u + w] & ~RXE_SELF;
   __syncthreads();  // the only block-wide barrier; after this the waves never meet again
 
+  zero_next_counters(p);
   const uint32_t wave = blockIdx.x * wpb + wib;
   const uint32_t stream = wave * L::SPW + g;
   bool alive = stream < p.n_streams;
+  if (wave * L::SPW < p.n_streams)
+    zero_final_rows(p, wave * L::SPW, p.n_streams - wave * L::SPW < L::SPW ? p.n_streams - wave * L::SPW : L::SPW, lane);
   const uint8_t* base = p.bytes + (size_t)(alive ? stream : 0) * p.stride;
   const bool aligned = (reinterpret_cast<uintptr_t>(base) & 3u) == 0;
 
@@ -725,7 +745,7 @@ __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
       am_word = 0;
     }
   }
-  // final active set: the row was zeroed by the host-side memset; set the listed bits
+  // final active set: the row was zeroed at the start of this kernel; set the listed bits
   if (p.final_active && alive) {
     const uint32_t* clist = lists + tog * L::CAP;
     uint32_t* row = p.final_active + (size_t)stream * p.nw64x2;
@@ -821,6 +841,7 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
   const uint32_t* __restrict__ ovf = p.ovf;
   unsigned long long st_active = 0, st_edges = 0, st_cost = 0, st_ovf = 0, st_dead = 0, fold_entries = 0;
 
+  zero_next_counters(p);
   for (uint32_t w = threadIdx.x; w < L::CMAPW; w += blockDim.x) cmapw[w] = p.byte_class[w];
   if (FOLD)
     for (uint32_t w = threadIdx.x; w < pin_words; w += blockDim.x) lds[L::CMAPW + w] = p.pin_tab[w];
@@ -831,6 +852,7 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
   if (stream0 >= p.n_streams) return;
   const uint32_t n_mine = p.n_streams - stream0 < (uint32_t)S ? p.n_streams - stream0 : (uint32_t)S;
   const bool owner = lane < n_mine;  // lane == stream slot it owns
+  zero_final_rows(p, stream0, n_mine, lane);
   // input windows: lane = 4*slot + part fetches bytes [64*chunk + 16*part, +16) of stream `slot`
   static_assert(S >= 1 && S <= (FOLD ? 64 : 32), "five-bit (FOLD: six-bit) stream slot; the window loader covers 16 streams per wave-load");
   constexpr uint32_t NLOAD = (S + 15) / 16;  // wave-loads per refill
@@ -1205,7 +1227,7 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
   if (PROF && lane == 0)
     for (int q = 0; q < 7; q++) atomicAdd(&p.counters[8 + q], t_sum[q]);
   if (FOLD && lane == 0 && fold_entries) atomicAdd(&p.counters[7], fold_entries);
-  // final active sets: rows were zeroed by the host-side memset; set the listed bits
+  // final active sets: the rows were zeroed at the start of this kernel; set the listed bits
   if (p.final_active && !spilled) {
     for (uint32_t li = lane; li < N; li += 64u) {
       const uint32_t e = clist[li];
@@ -1379,8 +1401,13 @@ __global__ void __launch_bounds__(256) rx_dfa_kernel(const RxParams p) {
   const uint32_t ncls = p.n_classes;
   unsigned long long st_active = 0, st_edges = 0;
 
+  zero_next_counters(p);
   const uint32_t stream = (blockIdx.x * wpb + wib) * 64u + lane;
   bool alive = stream < p.n_streams;
+  {
+    const uint32_t first = (blockIdx.x * wpb + wib) * 64u;
+    if (first < p.n_streams) zero_final_rows(p, first, p.n_streams - first < 64u ? p.n_streams - first : 64u, lane);
+  }
   const uint8_t* base = p.bytes + (size_t)(alive ? stream : 0) * p.stride;
   const bool aligned = (reinterpret_cast<uintptr_t>(base) & 3u) == 0;
   auto load16 = [&](uint32_t chunk, uint32_t (&o)[4]) {  // 16 bytes of this lane's own stream
@@ -1485,7 +1512,7 @@ __global__ void __launch_bounds__(256) rx_dfa_kernel(const RxParams p) {
       am_word = 0;
     }
   }
-  // final active sets: rows were zeroed by the host-side memset
+  // final active sets: the rows were zeroed at the start of this kernel
   if (p.final_active) {
     uint64_t mf = wballot(alive);
     while (mf) {
@@ -1510,34 +1537,38 @@ __global__ void __launch_bounds__(256) rx_dfa_kernel(const RxParams p) {
 // Kernel 6: register-resident active set, one wavefront per stream (few long streams)
 // =================================================================================================
 // The reference's own run is ONE lock-step pair of streams (testbench_BLK_Mem.sv:49-87): a single dependency chain
-// per stream, so what counts is the latency of a pass.  Here the active set never leaves the registers: lane L holds
-// at most one (state | accept flag) in a VGPR, EMPTY otherwise, and a pass is
-//     class of the byte (scalar, from a register window)  ->  ONE slice gather  ->  in-place update:
-//       the state stays (self loop)                         -> the lane keeps it,
-//       it moves on (one target, nothing else can reach it) -> the lane takes the target,
-//       it dies                                             -> the lane is free;
-//   no LDS list, no filter, no atomics.  What needs a lane of its own — a target next to a surviving state, a target
-//   that a second active state could also reach (RXE_MAYDUP: checked against all lanes with one compare), the targets
-//   of multi-target rows, what the folded `.*` state emits — goes through a short scalar loop (v_readlane, first free
-//   lane, v_writelane); on the shipped traces that is about one per pass.
-// FOLD as in the pack kernel (table in LDS, one uniform read per pass).  More than 64 active states: the stream is
-// handed to the wave kernel (resume mode) like in the group / pack kernels.
+// per stream, so what counts is the latency of a pass — and a lone wavefront pays ~10 cycles for EVERY instruction it
+// issues (measured: 45 instructions per pass = 500 cycles with the gather hitting L1) and more for a taken branch.
+// So the active set never leaves the registers and the common pass is a dozen straight-line instructions:
+//   * lane L holds at most one state id in a VGPR; a free lane holds the id `size`, whose row in the index is empty
+//     (accept states have empty rows anyway), so every lane gathers unconditionally — no EXEC masking, no branch;
+//   * the in-place update of a lane is PRECOMPUTED per (state, class) at load time (RxParams::regidx, rx_host.cpp):
+//     the state itself if it loops on the byte, its one target if nothing else can reach that target, else "free" —
+//     the pass is   gather 8 bytes  ->  v_and  ->  address  ->  next gather;
+//   * the byte classes of four passes come out of a register window with one v_readlane per four passes; what the
+//     folded `.*` state emits on each byte (already reduced to the targets that survive the NEXT byte) is looked up for
+//     256 passes at a time, vectorised, when the window is refilled, and costs one v_readlane per pass;
+//   * which lanes hold an accept state is a flag bit of the fast word (pulses are rare);
+//   * no LDS list, no filter, no atomics.  What needs a lane of its own — a target next to a surviving state, a target
+//     that a second active state could also reach (RXE_MAYDUP: compared against all lanes at once), the targets of
+//     multi-target rows, the folded state's targets — is flagged in the fast word and goes through a short scalar loop
+//     (v_readlane, first free lane, v_writelane): about every second pass on the busier shipped trace.
+// More than 64 active states: the stream is handed to the wave kernel (resume mode) like in the group / pack kernels.
 template <bool FOLD>
 __global__ void __launch_bounds__(64) rx_sym_reg_kernel(const RxParams p) {
-  constexpr uint32_t EMPTY = 0xFFFFFFFFu;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t* cmapw = lds;
   const uint8_t* cmap = reinterpret_cast<const uint8_t*>(cmapw);
-  const uint32_t* pintab = lds + 64u;
-  const uint32_t pin_words = FOLD ? p.n_classes * p.pin_cols : 0u;
-  for (uint32_t w = lane; w < 64u; w += 64u) cmapw[w] = p.byte_class[w];
-  for (uint32_t w = lane; w < pin_words; w += 64u) lds[64u + w] = p.pin_tab[w];
+  cmapw[lane] = p.byte_class[lane];
   wave_sync();
+  zero_next_counters(p);
   const uint32_t stream = blockIdx.x;
   if (stream >= p.n_streams) return;
-  const uint32_t ncls = p.n_classes;
-  const uint32_t* __restrict__ symidx = p.symidx_c;
+  zero_final_rows(p, stream, 1u, lane);
+  const uint32_t ncls = p.n_classes, ncls8 = ncls * 8u;
+  const uint32_t FREE = p.size;  // the empty row behind the index
+  const char* __restrict__ regidx = reinterpret_cast<const char*>(p.regidx);
   const uint32_t* __restrict__ ovf = p.ovf;
   ByteFeed feed;
   feed.base = p.bytes + (size_t)stream * p.stride;
@@ -1547,113 +1578,168 @@ __global__ void __launch_bounds__(64) rx_sym_reg_kernel(const RxParams p) {
     return (uint32_t)cmap[v & 0xFFu] | ((uint32_t)cmap[(v >> 8) & 0xFFu] << 8) | ((uint32_t)cmap[(v >> 16) & 0xFFu] << 16) |
            ((uint32_t)cmap[v >> 24] << 24);
   };
-  uint32_t cw = 0, nxt = feed.load_chunk(0, lane);  // classes of this lane's 4 bytes of the current 256-byte chunk; next chunk, raw
-  uint32_t e = lane == 0 ? p.state0_entry : EMPTY;    // FPGA.v:134-147: current = {state 0}
-  uint32_t am_word = 0;
   const uint32_t n_consume = p.n_consume < p.n_passes ? p.n_consume : p.n_passes;
+  // byte classes: lane j holds the classes of bytes 4j..4j+3 of the current 256-byte chunk (cw) and of the next (cwn);
+  // the raw chunk after that is in flight.  va[q]: what the folded state emits in pass (chunk base + 4j + q).
+  uint32_t cw = 0, cwn = classes(feed.load_chunk(0, lane)), raw = feed.load_chunk(1, lane);
+  uint32_t va[4] = {0u, 0u, 0u, 0u};
+  uint32_t e = lane == 0 ? 0u : FREE;             // FPGA.v:134-147: current = {state 0}
+  uint64_t macc = (p.state0_entry & RXE_ACCEPT) ? 1ull : 0ull;  // lanes that hold an accept state
+  uint32_t am_word = 0;
   bool handed_off = false;
   // shader clock the stream ran at (diagnostic; read by RX_OPT_VERBOSE): cycles and 100 MHz ticks of stream 0
   const unsigned long long t0c = __builtin_amdgcn_s_memtime(), t0r = __builtin_amdgcn_s_memrealtime();
 
-  for (uint32_t k = 0; k < p.n_passes; k++) {
-    // accept pulses of S_k (FPGA.v:210-226)
-    {
-      const bool acc = (e & (0x80000000u | RXE_ACCEPT)) == RXE_ACCEPT;  // EMPTY has bit 31 set
-      if (wballot(acc)) emit_events(p, acc, e & RXE_TGT_MASK, stream, k, lane, am_word);
-    }
-    if (k < n_consume) {
-      if ((k & 255u) == 0u) {
-        cw = classes(nxt);
-        nxt = feed.load_chunk((k >> 8) + 1u, lane);  // one chunk ahead
+  auto pulses = [&](uint32_t k) {  // accept pulses of S_k (FPGA.v:210-226); rare
+    const bool acc = (macc >> lane) & 1ull;
+    emit_events(p, acc, e, stream, k, lane, am_word);
+  };
+  auto store_anymatch = [&](uint32_t k) {
+    if (p.anymatch && lane == 0) p.anymatch[(size_t)stream * p.anymatch_stride + (k >> 5)] = am_word;
+    am_word = 0;
+  };
+  // {fast word, slice word} of every lane's state for a byte of class c
+  auto gather = [&](uint32_t c) {
+    return *reinterpret_cast<const uint2*>(regidx + (__umul24(e, ncls8) + (c << 3)));
+  };
+  // the rare part of a pass: everything that needs a lane of its own.  xs = slice words, e_in = S_k (for the hand-off).
+  auto slow = [&](uint32_t k, uint32_t xs, uint32_t e_in, uint32_t vA) {
+    const bool surv = (xs & RXE_SELF) != 0u;
+    const bool inl = FOLD ? (xs & (RXE_INLINE | RXE_PIN)) == RXE_INLINE : (xs & RXE_INLINE) != 0u;
+    uint64_t mx = wballot(inl && (surv || (xs & RXE_MAYDUP)));  // (an in-place target is neither)
+    uint64_t mo = wballot(xs & RXE_OVF);
+    uint64_t mfree = wballot(e == FREE);
+    bool full = false;
+    auto place = [&](uint32_t tw) {  // tw wave-uniform: target | RXE_ACCEPT | RXE_MAYDUP | RXE_PIN
+      if (FOLD && (tw & RXE_PIN)) return;
+      const uint32_t t = tw & RXE_TGT_MASK;
+      if ((tw & RXE_MAYDUP) && wballot(e == t)) return;  // already in the next set
+      if (mfree == 0ull) { full = true; return; }
+      const uint32_t dst = (uint32_t)__builtin_ctzll(mfree);
+      mfree &= mfree - 1ull;
+      if (lane == dst) e = t;
+      if (tw & RXE_ACCEPT) macc |= 1ull << dst;
+    };
+    auto place_list = [&](uint32_t off) {
+      const uint32_t cnt = ovf[off];
+      for (uint32_t j0 = 0; j0 < cnt; j0 += 64u) {
+        const uint32_t mine = j0 + lane < cnt ? ovf[off + 1u + j0 + lane] : 0u;  // one coalesced load per 64 targets
+        const uint32_t lim = cnt - j0 < 64u ? cnt - j0 : 64u;
+        for (uint32_t j = 0; j < lim; j++) place(bcast(mine, j));
       }
-      const uint32_t c = (bcast(cw, (k >> 2) & 63u) >> ((k & 3u) * 8u)) & 0xFFu;  // class of input_char
-      const uint32_t e_in = e;
-      const bool live = (e & (0x80000000u | RXE_ACCEPT)) == 0u;
-      uint32_t x = 0u;
-      if (live) x = symidx[__umul24(e & RXE_TGT_MASK, ncls) + c];  // the current byte's slice of that state's row
-      uint32_t vA = 0u;
-      if (FOLD && k >= 1u) {  // what the folded `.*` state emits, reduced to the targets that survive the next byte
-        uint32_t sel = ncls;
-        if (k + 1u < n_consume) {
-          const uint32_t k1 = k + 1u;
-          sel = (k1 & 255u) ? (bcast(cw, (k1 >> 2) & 63u) >> ((k1 & 3u) * 8u)) & 0xFFu
-                            : (uint32_t)__builtin_amdgcn_readfirstlane((int)cmap[bcast(nxt, 0) & 0xFFu]);
-        }
-        vA = pintab[c * p.pin_cols + sel];  // same address in every lane: one broadcast read
+    };
+    while (mx) {
+      const uint32_t src = (uint32_t)__builtin_ctzll(mx);
+      mx &= mx - 1ull;
+      place(bcast(xs, src));
+    }
+    while (mo) {
+      const uint32_t src = (uint32_t)__builtin_ctzll(mo);
+      mo &= mo - 1ull;
+      place_list(bcast(xs, src) & RXE_TGT_MASK);
+    }
+    if (FOLD) {
+      if (vA & RXE_INLINE) place(vA);
+      else if (vA & RXE_OVF) place_list(vA & RXE_TGT_MASK);
+    }
+    if (__builtin_expect(full, 0)) {
+      // more than 64 active states: hand the stream (S_k, k) to the wave kernel
+      unsigned long long b = 0;
+      if (lane == 0) b = atomicAdd(p.spill_count, 1ull);
+      const uint32_t slot = bcast((uint32_t)b, 0);
+      uint32_t* row = p.spill_rows + (size_t)slot * p.nw64x2;
+      for (uint32_t w = lane; w < p.nw64x2; w += 64u) row[w] = 0u;
+      if (lane == 0) {
+        p.spill_streams[slot] = stream;
+        p.spill_k[slot] = k;
+        if (p.anymatch) p.anymatch[(size_t)stream * p.anymatch_stride + (k >> 5)] = am_word;
       }
-      const bool surv = (x & RXE_SELF) != 0u;
-      const bool inl = FOLD ? (x & (RXE_INLINE | RXE_PIN)) == RXE_INLINE : (x & RXE_INLINE) != 0u;
-      const bool own = inl && !surv && !(x & RXE_MAYDUP);  // moves on, nothing else can reach the target: in place
-      e = surv ? e : (own ? (x & (RXE_TGT_MASK | RXE_ACCEPT)) : EMPTY);
-      uint64_t mx = wballot(inl && !own);  // targets that need a lane of their own / a duplicate check
-      uint64_t mo = wballot(x & RXE_OVF);
-      if (__builtin_expect((mx | mo) != 0ull || vA != 0u, 0)) {
-        uint64_t mfree = wballot(e == EMPTY);
-        bool full = false;
-        auto place = [&](uint32_t tw) {  // tw wave-uniform: target | RXE_ACCEPT | RXE_MAYDUP | RXE_PIN
-          if (FOLD && (tw & RXE_PIN)) return;
-          if ((tw & RXE_MAYDUP) && wballot(((e ^ tw) & RXE_TGT_MASK) == 0u)) return;  // already in the next set
-          if (mfree == 0ull) { full = true; return; }
-          const uint32_t dst = (uint32_t)__builtin_ctzll(mfree);
-          mfree &= mfree - 1ull;
-          if (lane == dst) e = tw & (RXE_TGT_MASK | RXE_ACCEPT);
-        };
-        auto place_list = [&](uint32_t off) {
-          const uint32_t cnt = ovf[off];
-          for (uint32_t j0 = 0; j0 < cnt; j0 += 64u) {
-            const uint32_t mine = j0 + lane < cnt ? ovf[off + 1u + j0 + lane] : 0u;  // one coalesced load per 64 targets
-            const uint32_t lim = cnt - j0 < 64u ? cnt - j0 : 64u;
-            for (uint32_t j = 0; j < lim; j++) place(bcast(mine, j));
-          }
-        };
-        while (mx) {
-          const uint32_t src = (uint32_t)__builtin_ctzll(mx);
-          mx &= mx - 1ull;
-          place(bcast(x, src));
-        }
-        while (mo) {
-          const uint32_t src = (uint32_t)__builtin_ctzll(mo);
-          mo &= mo - 1ull;
-          place_list(bcast(x, src) & RXE_TGT_MASK);
-        }
-        if (FOLD) {
-          if (vA & RXE_INLINE) place(vA);
-          else if (vA & RXE_OVF) place_list(vA & RXE_TGT_MASK);
-        }
-        if (__builtin_expect(full, 0)) {
-          // more than 64 active states: hand the stream (S_k, k) to the wave kernel
-          unsigned long long b = 0;
-          if (lane == 0) b = atomicAdd(p.spill_count, 1ull);
-          const uint32_t slot = bcast((uint32_t)b, 0);
-          uint32_t* row = p.spill_rows + (size_t)slot * p.nw64x2;
-          for (uint32_t w = lane; w < p.nw64x2; w += 64u) row[w] = 0u;
-          if (lane == 0) {
-            p.spill_streams[slot] = stream;
-            p.spill_k[slot] = k;
-            if (p.anymatch) p.anymatch[(size_t)stream * p.anymatch_stride + (k >> 5)] = am_word;
-          }
-          __threadfence();
-          wave_sync();
-          if (e_in != EMPTY) atomicOr(&row[(e_in & RXE_TGT_MASK) >> 5], 1u << (e_in & 31u));
-          if (FOLD && k >= 1u && lane == 0) atomicOr(&row[p.pin_state >> 5], 1u << (p.pin_state & 31u));
-          handed_off = true;
-          break;
-        }
+      __threadfence();
+      wave_sync();
+      if (e_in != FREE) atomicOr(&row[e_in >> 5], 1u << (e_in & 31u));
+      if (FOLD && k >= 1u && lane == 0) atomicOr(&row[p.pin_state >> 5], 1u << (p.pin_state & 31u));
+      handed_off = true;
+    }
+  };
+
+  uint2 x = n_consume ? gather(bcast(cwn, 0) & 0xFFu) : make_uint2(0u, 0u);  // the words for pass 0 are in flight
+  // One byte-consuming pass.  cn = class of the NEXT byte (scalar), vA = the folded state's emission in this pass.
+  auto pass = [&](uint32_t k, uint32_t cn, uint32_t vA) {
+    if (__builtin_expect(macc != 0ull, 0)) pulses(k);
+    const uint32_t xf = x.x, xs = x.y, e_in = e;
+    e = xf & RXE_TGT_MASK;                          // every lane's in-place update, precomputed
+    const uint64_t need = wballot((int)xf < 0);     // RXR_NEED
+    if (__builtin_expect(need == 0ull && vA == 0u, 1)) {
+      x = gather(cn);                                // the dependency chain of the stream ends here: gather k+1 is out
+      __builtin_amdgcn_sched_barrier(0);
+      macc = wballot(xf & RXR_ACC);                  // built while the gather is in flight
+    } else {
+      macc = wballot(xf & RXR_ACC);
+      slow(k, xs, e_in, vA);
+      x = gather(cn);
+    }
+  };
+
+  uint32_t k = 0;
+  while (k < n_consume && !handed_off) {  // k is a multiple of 256 here: next chunk of the stream
+    cw = cwn;
+    cwn = classes(raw);
+    raw = feed.load_chunk((k >> 8) + 2u, lane);  // two chunks ahead as bytes, one ahead as classes
+    if (FOLD) {
+      // the folded `.*` state's emissions for the 256 passes of this chunk, four per lane: table column = class of the
+      // NEXT byte (look-ahead pruning), except at the stream's last byte, whose sets are reported; none in pass 0
+      const uint32_t nxt_first = (uint32_t)__shfl_down((int)cw, 1);
+      const uint32_t next_chunk_first = bcast(cwn, 0);
+      const unsigned long long c5 = ((unsigned long long)(lane == 63u ? next_chunk_first : nxt_first) << 32) | cw;
+#pragma unroll
+      for (uint32_t q = 0; q < 4u; q++) {
+        const uint32_t kk = k + 4u * lane + q;
+        const uint32_t c0 = (uint32_t)(c5 >> (8u * q)) & 0xFFu, c1 = (uint32_t)(c5 >> (8u * q + 8u)) & 0xFFu;
+        va[q] = (kk >= 1u && kk < n_consume) ? p.pin_tab[c0 * p.pin_cols + (kk + 1u < n_consume ? c1 : ncls)] : 0u;
       }
     }
-    if (p.anymatch && ((k & 31u) == 31u || k + 1 == p.n_passes)) {
-      if (lane == 0) p.anymatch[(size_t)stream * p.anymatch_stride + (k >> 5)] = am_word;
-      am_word = 0;
+    const uint32_t kchunk = n_consume - k < 256u ? n_consume : k + 256u;
+    while (k + 4u <= kchunk && !handed_off) {  // four passes on the classes of one SGPR pair, no per-pass loop tests
+      const uint32_t gi = (k >> 2) & 63u;
+      const uint32_t c4 = bcast(cw, gi);
+      const uint32_t c4n = gi == 63u ? bcast(cwn, 0) : bcast(cw, gi + 1u);
+      pass(k, (c4 >> 8) & 0xFFu, FOLD ? bcast(va[0], gi) : 0u);
+      if (__builtin_expect(handed_off, 0)) break;
+      pass(k + 1u, (c4 >> 16) & 0xFFu, FOLD ? bcast(va[1], gi) : 0u);
+      if (__builtin_expect(handed_off, 0)) break;
+      pass(k + 2u, c4 >> 24, FOLD ? bcast(va[2], gi) : 0u);
+      if (__builtin_expect(handed_off, 0)) break;
+      pass(k + 3u, c4n & 0xFFu, FOLD ? bcast(va[3], gi) : 0u);
+      if (__builtin_expect(handed_off, 0)) break;
+      k += 4u;
+      if (p.anymatch && (k & 31u) == 0u) store_anymatch(k - 1u);
     }
+    while (k < kchunk && !handed_off) {  // the last one to three passes of the stream
+      const uint32_t gi = (k >> 2) & 63u, q = k & 3u;
+      const uint32_t c4 = bcast(cw, gi);
+      const uint32_t vq = q == 0u ? va[0] : (q == 1u ? va[1] : (q == 2u ? va[2] : va[3]));
+      pass(k, (c4 >> (8u * ((q + 1u) & 3u))) & 0xFFu, FOLD ? bcast(vq, gi) : 0u);  // (the look-ahead class is not used at the last byte)
+      if (handed_off) break;
+      k++;
+    }
+  }
+  if (!handed_off) {
+    bool unsaved = (k & 31u) != 0u;  // passes whose any-match bits are still in am_word
+    if (k < p.n_passes) {  // RX_MODE_FULL: pass N only looks for accept states
+      if (macc != 0ull) pulses(k);
+      k++;
+      unsaved = true;
+    }
+    if (p.anymatch && unsaved) store_anymatch(k - 1u);
   }
   if (stream == 0 && lane == 0) {
     p.counters[8] = __builtin_amdgcn_s_memtime() - t0c;
     p.counters[9] = __builtin_amdgcn_s_memrealtime() - t0r;
   }
-  // final active set: the row was zeroed by the host-side memset
+  // final active set: the row was zeroed at the start of this kernel
   if (p.final_active && !handed_off) {
     uint32_t* row = p.final_active + (size_t)stream * p.nw64x2;
-    if (e != EMPTY) atomicOr(&row[(e & RXE_TGT_MASK) >> 5], 1u << (e & 31u));
+    if (e != FREE) atomicOr(&row[e >> 5], 1u << (e & 31u));
     if (FOLD && n_consume >= 1u && lane == 0) atomicOr(&row[p.pin_state >> 5], 1u << (p.pin_state & 31u));
   }
 }
@@ -1755,15 +1841,18 @@ static int launch_fold(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s,
   const uint32_t ww = prune ? PackLayout<S, true, true>::WAVE_WORDS : PackLayout<S, false, true>::WAVE_WORDS;
   const uint32_t fixed = PackLayout<S, false, true>::CMAPW + p.n_classes * p.pin_cols;
   const uint32_t waves = (p.n_streams + S - 1) / S;
-  // wavefronts per block: the one that keeps the most wavefronts resident per CU (every block carries its own copy of
-  // the folding table), ties to the smaller block; enough blocks to reach every CU
-  uint32_t wpb = 0, best = 0;
+  // wavefronts per block (every block carries its own copy of the folding table): fewest rounds of resident blocks
+  // per CU first, then the fewest wavefronts on the busiest CU, then the larger block
+  uint32_t wpb = 0, best_rounds = ~0u, best_load = ~0u;
+  const uint32_t cus = cfg.cu_count > 0 ? (uint32_t)cfg.cu_count : 256u;
   for (uint32_t w = 1; w <= 8; w++) {
     const size_t bytes = (size_t)(fixed + w * ww) * 4u;
     if (bytes > lds_per_cu) break;
-    const uint32_t blocks = (uint32_t)std::min<size_t>(lds_per_cu / bytes, 32u / w);
-    const uint32_t resident = blocks * w;
-    if (resident > best && (w == 1 || (waves + w - 1) / w >= 256u)) { best = resident; wpb = w; }
+    const uint32_t resident = (uint32_t)std::min<size_t>(lds_per_cu / bytes, 32u / w);  // blocks per CU at a time
+    const uint32_t blocks = (waves + w - 1) / w;
+    const uint32_t per_cu = (blocks + cus - 1) / cus;  // blocks the busiest CU gets
+    const uint32_t rounds = (per_cu + resident - 1) / resident, load = per_cu * w;
+    if (rounds < best_rounds || (rounds == best_rounds && load <= best_load)) { best_rounds = rounds; best_load = load; wpb = w; }
   }
   if (wpb == 0) return (int)hipErrorInvalidValue;
   const uint32_t grid = (waves + wpb - 1) / wpb;
@@ -1791,7 +1880,7 @@ int rx_launch(const RxParams& p, const RxLaunchCfg& cfg, void* hip_stream) {
       int e;
       if (cfg.kernel == RX_KERNEL_SYM_REG) {  // one wavefront (= one block) per stream
         const bool fold = cfg.fold && p.pin_tab;
-        const uint32_t lds = (64u + (fold ? p.n_classes * p.pin_cols : 0u)) * 4u;
+        const uint32_t lds = 64u * 4u;  // the byte -> class map; the folding table is read with scalar loads
         e = fold ? launch_one(rx_sym_reg_kernel<true>, p, p.n_streams, 64u, lds, s)
                  : launch_one(rx_sym_reg_kernel<false>, p, p.n_streams, 64u, lds, s);
       } else if (cfg.kernel == RX_KERNEL_DFA) {
@@ -1832,6 +1921,8 @@ int rx_launch(const RxParams& p, const RxLaunchCfg& cfg, void* hip_stream) {
       // the count is read on the device, so no host round-trip)
       RxParams r = p;
       r.resume = 1;
+      r.zero_next = nullptr;  // the first launch of the pair has done it
+      r.zero_words = 0;
       const uint32_t wpb = cfg.block_threads / 64u;
       uint32_t grid = (p.n_streams + wpb - 1) / wpb;
       const uint32_t fill = (cfg.cu_count > 0 ? (uint32_t)cfg.cu_count : 256u) * 8u;  // enough blocks to fill the chip
