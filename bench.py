@@ -296,9 +296,36 @@ def main():
         hplan.upload(rows)
         hplan.launch()
         hres = hplan.download()
-        host_to_host_s = time.perf_counter() - t_h
+        serial_s = time.perf_counter() - t_h
         assert hres["stats"]["n_events"] == n_events
+        # the same through rx_plan_run: blocks of streams pipelined over HIP streams, caller buffers page-locked once
+        # (first call) and then moved by DMA without staging copies
+        hplan.run(rows)
+        hplan.run(rows)  # (the first call page-locks the buffers and lets AUTO probe; the second touches every page)
+        host_to_host_s = 1e9
+        for _ in range(3):
+            t_h = time.perf_counter()
+            hres = hplan.run(rows)
+            host_to_host_s = min(host_to_host_s, time.perf_counter() - t_h)
+        assert hres["stats"]["n_events"] == n_events and np.array_equal(hres["events"], res["events"])
+        assert np.array_equal(hres["final_active"], res["final_active"]) and np.array_equal(hres["anymatch"], res["anymatch"])
         hplan.close()
+        out["host_to_host_serial_pageable_gbit_s"] = round(8.0 * ns * sl / serial_s / 1e9, 3)
+        # the link's floor for this call: input up + every output down over one PCIe link that carries ~56 GB/s in either
+        # direction or both together (tools/copybw.py on the MI355X box); the final sets are 1.2 KB of bitmask per stream
+        link_bytes = ns * sl + ns * nfa.nw64 * 8 + ns * ((npass + 31) // 32) * 4 + n_events * 12
+        out["host_to_host_link_floor_gbit_s"] = round(8.0 * ns * sl / (link_bytes / 56e9) / 1e9, 1)
+        nplan = rx.Plan(nfa, ns, sl, want_match_count=False, want_anymatch=True, want_final=False, **common)
+        nplan.run(rows)
+        nplan.run(rows)
+        best = 1e9
+        for _ in range(3):
+            t_h = time.perf_counter()
+            nres = nplan.run(rows)
+            best = min(best, time.perf_counter() - t_h)
+        out["host_to_host_no_final_sets_gbit_s"] = round(8.0 * ns * sl / best / 1e9, 3)
+        assert nres["stats"]["n_events"] == n_events
+        nplan.close()
         out["host_to_host_gbit_s"] = round(8.0 * ns * sl / host_to_host_s / 1e9, 3)
 
         # north-star form: ONE WAVEFRONT OWNS ONE STREAM and reads row_ptr pairs + whole rows from the unchanged CSR

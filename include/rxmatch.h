@@ -254,7 +254,22 @@ int rx_plan_kernel_times(rx_plan* plan, uint32_t* n_launches, double* sum_ms, do
                          double* max_ms);
 /* Copy the last launch's results to the caller's arrays (sorted events, counts, ...). */
 int rx_plan_download(rx_plan* plan, rx_result* res);
+/* Host buffers in, host results out, in ONE call — the same results as rx_plan_upload + rx_plan_launch +
+ * rx_plan_download, but pipelined: the batch is cut into up to 4 blocks of streams, each with its own HIP stream, so
+ * that the upload of block i+1, the kernel of block i and the download of block i-1 overlap (PCIe is full duplex;
+ * blocks of different streams share the GPU).  Host memory that is page-locked — registered with rx_host_register, or
+ * allocated pinned by the caller — is read and written by DMA directly; pageable memory works too, at the speed of the
+ * runtime's staging copies.  The plan must have been created for at least n_streams / stream_len; the caller's start
+ * sets are not supported here (streams start from reset).  Blocks report accept events into equal shares of the plan's
+ * event capacity (an overflow in any share sets events_overflow). */
+int rx_plan_run(rx_plan* plan, const uint8_t* bytes, size_t n_streams, size_t stream_len, size_t stride, rx_result* res);
 void rx_plan_free(rx_plan* plan);
+
+/* Page-lock / release a host buffer (hipHostRegister) so that rx_plan_run / rx_plan_upload / rx_plan_download move it
+ * by DMA without a staging copy.  Register long-lived buffers once; registration itself costs about as much as
+ * copying the buffer. */
+int rx_host_register(void* ptr, size_t bytes);
+int rx_host_unregister(void* ptr);
 
 /* ---- device helpers (so callers need no HIP binding of their own) ------------------------ */
 int rx_device_count(int* n);

@@ -384,6 +384,15 @@ struct rx_plan {
   double probe_active = 0;     // active states per stream-byte seen by the probe
   RxParams params{};
   RxLaunchCfg cfg{};
+  // rx_plan_run: blocks of streams in flight on their own HIP streams
+  struct Pipe {
+    unsigned long long* d_set = nullptr;   // {counters[16], match_count_total[size]} of the block (device)
+    unsigned long long* h_set = nullptr;   // the same, page-locked host memory
+    hipEvent_t up = nullptr;               // the block's input is in HBM
+    hipEvent_t k0 = nullptr, k1 = nullptr; // bracket the block's kernels
+  };
+  std::vector<Pipe> pipes;
+  hipStream_t s_in = nullptr, s_k = nullptr, s_out = nullptr;  // uploads / kernels / downloads of rx_plan_run
   // one hipEvent pair per launch since the last rx_plan_kernel_times() call
   std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
   size_t n_timed = 0;
@@ -487,6 +496,16 @@ extern "C" void rx_plan_free(rx_plan* p) {
   (void)hipFree(p->d_spill_k);
   (void)hipFree(p->d_spill_rows);
   for (auto& e : p->evs) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (auto& q : p->pipes) {
+    (void)hipFree(q.d_set);
+    if (q.h_set) (void)hipHostFree(q.h_set);
+    if (q.up) (void)hipEventDestroy(q.up);
+    if (q.k0) (void)hipEventDestroy(q.k0);
+    if (q.k1) (void)hipEventDestroy(q.k1);
+  }
+  if (p->s_in) (void)hipStreamDestroy(p->s_in);
+  if (p->s_k) (void)hipStreamDestroy(p->s_k);
+  if (p->s_out) (void)hipStreamDestroy(p->s_out);
   if (have_prev) (void)hipSetDevice(prev);
   delete p;
 }
@@ -743,13 +762,10 @@ static int auto_probe(rx_plan* p) {
   return RX_OK;
 }
 
-extern "C" int rx_plan_launch(rx_plan* p) {
-  RX_TRY
-  if (!p) return RX_EINVAL;
-  if (!p->have_input) return RX_ESTATE;
-  int dev;
-  int rc = bind_device(p->device, &dev);
-  if (rc) return rc;
+// Everything a launch decides before anything is enqueued for it: kernel arguments for the whole batch (p->params),
+// kernel choice (AUTO's probe runs here when its decision is not valid for the batch) and launch geometry (p->cfg).
+static int prepare_launch(rx_plan* p) {
+  int rc;
   const RxHostNfa& h = p->nfa->h;
   RxParams& a = p->params;
   fill_common(p, a);
@@ -840,6 +856,19 @@ extern "C" int rx_plan_launch(rx_plan* p) {
     a.dfa_pool_chunks = t.dfa_pool_chunks;
     a.dfa_hash_mask = t.dfa_hash_mask;
   }
+  return RX_OK;
+}
+
+extern "C" int rx_plan_launch(rx_plan* p) {
+  RX_TRY
+  if (!p) return RX_EINVAL;
+  if (!p->have_input) return RX_ESTATE;
+  int dev;
+  int rc = bind_device(p->device, &dev);
+  if (rc) return rc;
+  if ((rc = prepare_launch(p))) return rc;
+  const RxHostNfa& h = p->nfa->h;
+  RxParams& a = p->params;
 
   // counters + match_count_total: the other set, which the previous launch's kernel has zeroed (or, after a probe or
   // the plan's creation, a reset enqueued here); this launch's kernel zeroes the one after
@@ -918,6 +947,37 @@ static bool ev_less(const rx_event& a, const rx_event& b) {
   return a.state < b.state;
 }
 
+// Canonical order (stream, k, state) of the events of streams [lo, lo + n_streams).  The device hands them over in
+// arrival order — per stream already ascending in k (a wavefront's passes allocate their slots one after the other) —
+// so a stable counting sort by stream does nearly everything in O(n); an insertion sort per stream finishes equal-k
+// runs and anything an unusual kernel left out of order.  (std::sort on 75 000 events took 5 ms of a 8 ms call.)
+static void sort_events(std::vector<rx_event>& ev, uint32_t lo, size_t n_streams, std::vector<rx_event>& scratch) {
+  const size_t n = ev.size();
+  if (n < 2) return;
+  if (n < 64 || n_streams > 8 * n + 1024) { std::sort(ev.begin(), ev.end(), ev_less); return; }
+  std::vector<uint32_t> at(n_streams + 1, 0u);
+  for (const rx_event& e : ev) {
+    if (e.stream < lo || e.stream - lo >= n_streams) { std::sort(ev.begin(), ev.end(), ev_less); return; }  // not ours: be safe
+    at[e.stream - lo + 1]++;
+  }
+  for (size_t i = 0; i < n_streams; i++) at[i + 1] += at[i];
+  scratch.resize(n);
+  {
+    std::vector<uint32_t> pos(at.begin(), at.end() - 1);
+    for (const rx_event& e : ev) scratch[pos[e.stream - lo]++] = e;
+  }
+  for (size_t st = 0; st < n_streams; st++) {
+    const uint32_t b = at[st], e = at[st + 1];
+    for (uint32_t i = b + 1; i < e; i++) {
+      const rx_event x = scratch[i];
+      uint32_t j = i;
+      while (j > b && ev_less(x, scratch[j - 1])) { scratch[j] = scratch[j - 1]; j--; }
+      scratch[j] = x;
+    }
+  }
+  ev.swap(scratch);
+}
+
 // rx_result as the caller's version of the header laid it out (see read_opts)
 static size_t result_bytes(const rx_result* res) {
   return res->struct_size ? std::min<size_t>(res->struct_size, sizeof(rx_result)) : sizeof(rx_result);
@@ -987,9 +1047,9 @@ static int plan_download(rx_plan* p, rx_result* res) {
   res->events_overflow = cnt[0] > p->events_cap ? 1u : 0u;
   res->n_events = 0;
   if (res->events && res->events_cap && captured) {
-    std::vector<rx_event> tmp(captured);
+    std::vector<rx_event> tmp(captured), scratch;
     HIPCHK(hipMemcpy(tmp.data(), p->d_events, captured * sizeof(rx_event), hipMemcpyDeviceToHost));
-    std::sort(tmp.begin(), tmp.end(), ev_less);  // device order is arrival order; canonical = (stream,k,state)
+    sort_events(tmp, p->params.stream_base, p->n_streams, scratch);  // device order is arrival order; canonical = (stream,k,state)
     const size_t n = std::min(captured, res->events_cap);
     memcpy(res->events, tmp.data(), n * sizeof(rx_event));
     res->n_events = n;
@@ -1007,7 +1067,9 @@ static int plan_download(rx_plan* p, rx_result* res) {
     if (!p->want_am) return RX_ESTATE;
     const size_t need = (size_t)((st.n_passes + 31) / 32);
     if (res->anymatch_stride < need) return RX_EINVAL;
-    if (need)
+    if (need && res->anymatch_stride == p->am_stride)  // same pitch on both sides: one flat copy (2-D copies go row by row)
+      HIPCHK(hipMemcpy(res->anymatch, p->d_am, p->n_streams * p->am_stride * 4, hipMemcpyDeviceToHost));
+    else if (need)
       HIPCHK(hipMemcpy2D(res->anymatch, res->anymatch_stride * 4, p->d_am, p->am_stride * 4, need * 4, p->n_streams,
                          hipMemcpyDeviceToHost));
   }
@@ -1016,6 +1078,214 @@ static int plan_download(rx_plan* p, rx_result* res) {
     HIPCHK(hipMemcpy(res->final_active, p->d_final, p->n_streams * p->params.nw64x2 * sizeof(uint32_t),
                      hipMemcpyDeviceToHost));
   }
+  return RX_OK;
+}
+
+// ---- pipelined host-to-host run ---------------------------------------------------------------------
+extern "C" int rx_host_register(void* ptr, size_t bytes) {
+  if (!ptr || !bytes) return RX_EINVAL;
+  hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+  if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return RX_OK; }
+  if (e != hipSuccess) return hip_fail(e, "hipHostRegister");
+  return RX_OK;
+}
+extern "C" int rx_host_unregister(void* ptr) {
+  if (!ptr) return RX_EINVAL;
+  hipError_t e = hipHostUnregister(ptr);
+  if (e != hipSuccess) return hip_fail(e, "hipHostUnregister");
+  return RX_OK;
+}
+
+static int plan_run(rx_plan* p, const uint8_t* bytes, size_t n_streams, size_t stream_len, size_t stride, rx_result* res);
+
+extern "C" int rx_plan_run(rx_plan* p, const uint8_t* bytes, size_t n_streams, size_t stream_len, size_t stride,
+                           rx_result* caller) {
+  RX_TRY
+  if (!p || !caller || (!bytes && stream_len)) return RX_EINVAL;
+  rx_result full{};
+  const size_t have = result_bytes(caller);
+  memcpy(&full, caller, have);
+  const int rc = plan_run(p, bytes, n_streams, stream_len, stride, &full);
+  memcpy(caller, &full, have);
+  return rc;
+  RX_CATCH
+}
+
+static int plan_run(rx_plan* p, const uint8_t* bytes, size_t n_streams, size_t stream_len, size_t stride, rx_result* res) {
+  int dev;
+  int rc = bind_device(p->device, &dev);
+  if (rc) return rc;
+  if ((rc = set_batch(p, n_streams, stream_len, stride))) return rc;
+  const RxHostNfa& h = p->nfa->h;
+  const uint32_t size = h.size;
+  const size_t nw64 = ((size_t)size + 63) / 64, set_words = 16 + (size_t)size;
+  if ((res->match_count && !p->want_mc) || (res->anymatch && !p->want_am) || (res->final_active && !p->want_final)) return RX_ESTATE;
+  // input buffer of the plan, rows at a 4-byte-aligned pitch
+  const size_t pitch = (stream_len + 3) & ~(size_t)3;
+  const size_t need = std::max<size_t>(n_streams * pitch, 4);
+  if (need > p->d_in_own_bytes) {
+    (void)hipFree(p->d_in_own);
+    p->d_in_own = nullptr;
+    p->d_in_own_bytes = 0;
+    HIPCHK(hipMalloc((void**)&p->d_in_own, need));
+    p->d_in_own_bytes = need;
+  }
+  p->d_in = p->d_in_own;
+  p->stride = pitch;
+  // blocks of streams: 32 768 or more each (smaller launches leave SIMDs idle), at most eight, sizes a multiple of
+  // 1 024 (lock-step pairs stay together).  Three HIP streams: uploads, kernels, downloads — a copy runs beside a
+  // kernel, the two copy directions share the link (measured on the MI355X box: 56 GB/s in either direction or in
+  // both together), so the pipeline's floor is (input + output bytes) / 56 GB/s.
+  size_t n_blocks = std::min<size_t>(8, std::max<size_t>(1, n_streams / 32768));
+  size_t per = (n_streams + n_blocks - 1) / n_blocks;
+  per = (per + 1023) & ~(size_t)1023;
+  n_blocks = (n_streams + per - 1) / per;
+  if (!p->s_in) {
+    HIPCHK(hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&p->s_k, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking));
+  }
+  while (p->pipes.size() < n_blocks) {
+    rx_plan::Pipe q;
+    HIPCHK(hipMalloc((void**)&q.d_set, set_words * sizeof(unsigned long long)));
+    HIPCHK(hipHostMalloc((void**)&q.h_set, set_words * sizeof(unsigned long long), hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&q.up, hipEventDisableTiming));
+    HIPCHK(hipEventCreate(&q.k0));
+    HIPCHK(hipEventCreate(&q.k1));
+    p->pipes.push_back(q);
+  }
+  auto upload = [&](size_t b) -> int {
+    const size_t s0 = b * per, cnt = std::min(per, n_streams - s0);
+    if (stream_len) {
+      if (stride == pitch && stream_len == pitch)
+        HIPCHK(hipMemcpyAsync(p->d_in_own + s0 * pitch, bytes + s0 * stride, cnt * pitch, hipMemcpyHostToDevice, p->s_in));
+      else
+        HIPCHK(hipMemcpy2DAsync(p->d_in_own + s0 * pitch, pitch, bytes + s0 * stride, stride, stream_len, cnt, hipMemcpyHostToDevice,
+                                p->s_in));
+    }
+    HIPCHK(hipEventRecord(p->pipes[b].up, p->s_in));
+    return RX_OK;
+  };
+  // block 0 goes up first: AUTO's probe (when its decision is not valid for this batch) reads a corner of it
+  if ((rc = upload(0))) return rc;
+  if (!p->auto_decided) HIPCHK(hipStreamSynchronize(p->s_in));
+  if ((rc = prepare_launch(p))) return rc;
+  if (p->opts.collect_stats == 2 && (per & 1)) return RX_EINVAL;
+  HIPCHK(hipStreamSynchronize(p->stream));  // (the probe ran on the plan's own stream)
+  const size_t ev_share = p->events_cap / n_blocks;
+  const size_t am_need = (size_t)((p->params.n_passes + 31) / 32);
+  if (res->anymatch && res->anymatch_stride < am_need) return RX_EINVAL;
+  const bool two_tier = p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK ||
+                        p->cfg.kernel == RX_KERNEL_DFA || p->cfg.kernel == RX_KERNEL_SYM_REG;
+  for (size_t b = 1; b < n_blocks; b++)  // all uploads are queued before any download (both use the same link)
+    if ((rc = upload(b))) return rc;
+  for (size_t b = 0; b < n_blocks; b++) {
+    rx_plan::Pipe& q = p->pipes[b];
+    const size_t s0 = b * per, cnt = std::min(per, n_streams - s0);
+    RxParams a = p->params;  // the block's view of the batch
+    RxLaunchCfg cfg = p->cfg;
+    a.bytes = p->d_in_own + s0 * pitch;
+    a.n_streams = (uint32_t)cnt;
+    a.stream_base = (uint32_t)s0;
+    a.events = ev_share ? p->d_events + b * ev_share : nullptr;
+    a.events_cap = (uint32_t)ev_share;
+    a.counters = q.d_set;
+    a.match_count_total = q.d_set + 16;
+    a.zero_next = nullptr;
+    a.zero_words = 0;
+    if (a.match_count) a.match_count += s0 * size;
+    if (a.anymatch) a.anymatch += s0 * p->am_stride;
+    if (a.final_active) a.final_active += s0 * (size_t)a.nw64x2;
+    if (two_tier) {
+      a.spill_count = q.d_set + 3;
+      a.spill_streams += s0;
+      a.spill_k += s0;
+      a.spill_rows += s0 * (size_t)a.nw64x2;
+    }
+    const uint32_t lanes = cfg.group_lanes;
+    if ((rc = rx_pick_launch(cfg.kernel, size, a.n_streams, p->tab.cu_count, p->tab.lds_per_cu, &a, &cfg))) return rc;
+    cfg.group_lanes = lanes;
+    HIPCHK(hipMemsetAsync(q.d_set, 0, set_words * sizeof(unsigned long long), p->s_k));
+    if (p->want_mc) HIPCHK(hipMemsetAsync(p->d_mc + s0 * size, 0, cnt * size * sizeof(uint32_t), p->s_k));
+    HIPCHK(hipStreamWaitEvent(p->s_k, q.up, 0));
+    HIPCHK(hipEventRecord(q.k0, p->s_k));
+    hipError_t e = (hipError_t)rx_launch(a, cfg, p->s_k);
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    HIPCHK(hipEventRecord(q.k1, p->s_k));
+    // results of the block straight into the caller's arrays
+    HIPCHK(hipStreamWaitEvent(p->s_out, q.k1, 0));
+    HIPCHK(hipMemcpyAsync(q.h_set, q.d_set, set_words * sizeof(unsigned long long), hipMemcpyDeviceToHost, p->s_out));
+    if (res->final_active)
+      HIPCHK(hipMemcpyAsync(res->final_active + s0 * nw64, p->d_final + s0 * (size_t)a.nw64x2, cnt * nw64 * sizeof(uint64_t),
+                            hipMemcpyDeviceToHost, p->s_out));
+    if (res->anymatch && am_need) {
+      if (res->anymatch_stride == p->am_stride)  // same pitch on both sides: one flat copy (2-D copies go row by row)
+        HIPCHK(hipMemcpyAsync(res->anymatch + s0 * p->am_stride, p->d_am + s0 * p->am_stride, cnt * p->am_stride * 4,
+                              hipMemcpyDeviceToHost, p->s_out));
+      else
+        HIPCHK(hipMemcpy2DAsync(res->anymatch + s0 * res->anymatch_stride, res->anymatch_stride * 4, p->d_am + s0 * p->am_stride,
+                                p->am_stride * 4, am_need * 4, cnt, hipMemcpyDeviceToHost, p->s_out));
+    }
+    if (res->match_count)
+      HIPCHK(hipMemcpyAsync(res->match_count + s0 * size, p->d_mc + s0 * size, cnt * size * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                            p->s_out));
+    // events of the block: the count is only known on the device, so its whole share comes over — unless that is
+    // large, in which case they are fetched after the block has finished (below)
+  }
+  const bool verbose = (p->opts.flags & RX_OPT_VERBOSE) != 0;
+  const auto w_issued = std::chrono::steady_clock::now();
+  HIPCHK(hipStreamSynchronize(p->s_out));
+  if (verbose)
+    fprintf(stderr, "[rxmatch] run: %zu block(s) of <= %zu streams, all results down %.3f ms after the last enqueue\n", n_blocks, per,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w_issued).count());
+  // collect: counters, events (sorted per block; blocks are in stream order, so the concatenation is sorted)
+  rx_stats& st = res->stats;
+  st = rx_stats{};
+  st.n_passes = p->params.n_passes;
+  st.kernel_used = p->cfg.kernel;
+  st.lanes_used = (p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK) ? p->cfg.group_lanes : 0u;
+  st.variant = (p->cfg.stats ? RX_VARIANT_STATS : 0u) |
+               (p->cfg.kernel == RX_KERNEL_SYM_PACK && p->cfg.prune && !p->cfg.stats && p->tab.ovf_dir ? RX_VARIANT_PRUNE : 0u) |
+               (p->cfg.fold ? RX_VARIANT_FOLD : 0u);
+  res->n_events = 0;
+  res->events_overflow = 0;
+  if (res->match_count_total) memset(res->match_count_total, 0, (size_t)size * sizeof(uint64_t));
+  std::vector<rx_event> tmp, scratch;
+  unsigned long long spilled = 0, pair_cost = 0;
+  for (size_t b = 0; b < n_blocks; b++) {
+    rx_plan::Pipe& q = p->pipes[b];
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, q.k0, q.k1);
+    st.kernel_ms += ms;
+    st.n_launches += two_tier ? 2 : 1;
+    const unsigned long long* cnt = q.h_set;
+    st.n_events += cnt[0];
+    st.sum_active += cnt[1];
+    st.sum_edges += cnt[2];
+    spilled += cnt[3];
+    pair_cost += cnt[4];
+    if (res->match_count_total)
+      for (uint32_t i = 0; i < size; i++) res->match_count_total[i] += cnt[16 + i];
+    const size_t captured = (size_t)std::min<unsigned long long>(cnt[0], ev_share);
+    if (cnt[0] > ev_share && res->events) res->events_overflow = 1u;
+    if (res->events && res->events_cap && captured) {
+      tmp.resize(captured);
+      HIPCHK(hipMemcpy(tmp.data(), p->d_events + b * ev_share, captured * sizeof(rx_event), hipMemcpyDeviceToHost));
+      sort_events(tmp, (uint32_t)(b * per), std::min(per, n_streams - b * per), scratch);
+      const size_t room = res->events_cap - res->n_events, n = std::min(captured, room);
+      memcpy(res->events + res->n_events, tmp.data(), n * sizeof(rx_event));
+      res->n_events += n;
+      if (n < captured) res->events_overflow = 1u;
+    }
+  }
+  if (p->cfg.stats) {
+    st.alg_bytes = (uint64_t)p->params.n_consume * n_streams + 8 * st.sum_active + 4 * st.sum_edges +
+                   (uint64_t)n_streams * ((st.n_passes + 7) / 8) + 12 * st.n_events;
+    if (p->params.pair_cycles && spilled == 0)
+      st.tb_cycles = (n_streams / 2) * (1 + (uint64_t)p->params.n_consume * size) + pair_cost;
+  }
+  p->launched = false;  // (nothing is left on the device for rx_plan_download)
+  p->sets_clean = false;
   return RX_OK;
 }
 

@@ -384,6 +384,7 @@ int rxh_build(const uint32_t* W, size_t nwords, uint32_t size_or_0, RxHostNfa* o
       }
     // one all-zero row behind the per-class index: the id `size` is the register kernel's "free lane" (rx_kernels.hip)
     out->symidx_c.resize((size_t)(size + 1u) * ncls, 0u);
+    if (have_dir) out->symidx_p.resize((size_t)(size + 1u) * ncls, 0u);
     if (!out->pin_tab.empty())
       for (uint32_t k = 0; k < ncls; k++)
         for (uint32_t n = 0; n <= ncls; n++) {

@@ -74,6 +74,7 @@ struct RxParams {
   uint32_t n_passes;            // accept checks per stream
   uint32_t n_consume;           // bytes consumed per stream (= n_passes in tb-compat, N in full mode)
   uint32_t k_base;
+  uint32_t stream_base;         // added to every reported stream id (rx_plan_run launches a batch in chunks of streams)
   uint32_t state0_entry;        // list entry for reset state 0 (accept flag folded in)
   const uint32_t* init_active;  // optional [n_streams][2*nw64] start bitmasks (u64 rows viewed as u32)
   uint32_t nw64x2;              // u32 words per init/final row = 2*ceil(size/64)

@@ -111,7 +111,7 @@ __device__ __forceinline__ void emit_events(const RxParams& p, bool acc, uint32_
     const unsigned long long idx = base + rank_below(ma);
     if (p.events && idx < p.events_cap) {
       rx_event e;
-      e.stream = stream;
+      e.stream = p.stream_base + stream;
       e.k = p.k_base + k;
       e.state = state;
       p.events[idx] = e;

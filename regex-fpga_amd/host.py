@@ -64,7 +64,7 @@ ABI_SYMBOLS = ["rx_nfa_dfa_info", "rx_nfa_dfa_reset", "rx_compile_patterns", "rx
                "rx_nfa_get_info", "rx_nfa_words", "rx_nfa_free", "rx_trace_load_mem", "rx_free", "rx_match",
                "rx_match_sharded", "rx_plan_create", "rx_plan_upload", "rx_plan_set_device_input",
                "rx_plan_set_init_active", "rx_plan_launch", "rx_plan_sync", "rx_plan_kernel_times", "rx_plan_download", "rx_plan_free",
-               "rx_device_count", "rx_device_name"]
+               "rx_device_count", "rx_device_name", "rx_plan_run", "rx_host_register", "rx_host_unregister"]
 
 _lib = None
 
@@ -136,6 +136,9 @@ def lib():
     L.rx_plan_kernel_times.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                        C.POINTER(C.c_double)]
     L.rx_plan_download.argtypes = [vp, C.POINTER(_Result)]
+    L.rx_plan_run.argtypes = [vp, vp, sz, sz, sz, C.POINTER(_Result)]
+    L.rx_host_register.argtypes = [vp, sz]
+    L.rx_host_unregister.argtypes = [vp]
     L.rx_plan_free.argtypes = [vp]
     L.rx_plan_free.restype = None
     L.rx_device_count.argtypes = [C.POINTER(i32)]
@@ -413,8 +416,50 @@ class Plan:
         _chk(lib().rx_plan_download(self._h, C.byref(out.r)), "rx_plan_download")
         return out.as_dict()
 
+    def run(self, data, want_total=True, register=True):
+        """rx_plan_run(): host rows in, host results out in one pipelined call (upload, kernel and download of blocks of
+        streams overlap).  The output arrays live as long as the plan and are page-locked once (`register`), and so is
+        `data` — pass the same array again and it moves by DMA.  Returns the same dict as download(); its arrays are
+        overwritten by the next run()."""
+        data, stride = _as_rows(data)
+        ns, sl = data.shape
+        key = (ns, sl, want_total)
+        if getattr(self, "_run_key", None) != key:
+            self._release_run_buffers()
+            wmc, wam, wfin = self.want
+            self._run_out = _Out(self.nfa, ns, sl, self.mode, self.events_cap, wmc, want_total, wam, wfin)
+            self._run_key = key
+            self._run_reg = []
+            if register:
+                for arr in (self._run_out.ev, self._run_out.mc, self._run_out.am, self._run_out.fin):
+                    if arr is not None and arr.nbytes:
+                        _chk(lib().rx_host_register(arr.ctypes.data, arr.nbytes), "rx_host_register")
+                        self._run_reg.append(arr.ctypes.data)
+        if register and data.nbytes and getattr(self, "_run_in", None) != (data.ctypes.data, data.nbytes):
+            if getattr(self, "_run_in", None):
+                lib().rx_host_unregister(self._run_in[0])
+            _chk(lib().rx_host_register(data.ctypes.data, data.nbytes), "rx_host_register")
+            self._run_in = (data.ctypes.data, data.nbytes)
+            self._run_in_keep = data
+        self.n_streams, self.stream_len = ns, sl
+        out = self._run_out
+        _chk(lib().rx_plan_run(self._h, data.ctypes.data, ns, sl, stride, C.byref(out.r)), "rx_plan_run")
+        return out.as_dict()
+
+    def _release_run_buffers(self):
+        for addr in getattr(self, "_run_reg", []):
+            lib().rx_host_unregister(addr)
+        self._run_reg = []
+        if getattr(self, "_run_in", None):
+            lib().rx_host_unregister(self._run_in[0])
+            self._run_in = None
+            self._run_in_keep = None
+        self._run_out = None
+        self._run_key = None
+
     def close(self):
         if self._h:
+            self._release_run_buffers()
             lib().rx_plan_free(self._h)
             self._h = None
 

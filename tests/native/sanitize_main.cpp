@@ -30,9 +30,71 @@ int main(int argc, char** argv) {
   // states or have an edge on that class, and its last entry is the full list
   auto check_derived = [](const RxHostNfa& a) -> int {
     const uint32_t ncls = a.n_classes;
-    CHECK(ncls >= 1 && ncls <= 256 && a.symidx_c.size() == (size_t)a.size * ncls);
+    // (the per-class index has one extra, empty row — the register kernel's "free lane" — and carries RXE_MAYDUP)
+    CHECK(ncls >= 1 && ncls <= 256 && a.symidx_c.size() == (size_t)(a.size + 1u) * ncls);
+    for (uint32_t k = 0; k < ncls; k++) CHECK(a.symidx_c[(size_t)a.size * ncls + k] == 0u);
     for (uint32_t s = 0; s < a.size; s += (a.size > 4000 ? 7 : 1))
-      for (int c = 0; c < 256; c++) CHECK(a.symidx[(size_t)s * 256 + c] == a.symidx_c[(size_t)s * ncls + a.byte_class[c]]);
+      for (int c = 0; c < 256; c++)
+        CHECK(a.symidx[(size_t)s * 256 + c] == (a.symidx_c[(size_t)s * ncls + a.byte_class[c]] & ~RXE_MAYDUP));
+    // RXE_MAYDUP: set on an inline target exactly when a second entered state reaches it on the class (or it loops on it)
+    {
+      std::vector<uint8_t> entered(a.size, 0);
+      for (uint32_t e = 0; e < a.nnz; e++) entered[a.col()[e] & 0xFFFFFFu] = 1;
+      for (uint32_t s = 0; s < a.size; s += (a.size > 4000 ? 31 : 3))
+        for (uint32_t k = 0; k < ncls; k++) {
+          const uint32_t w = a.symidx_c[(size_t)s * ncls + k];
+          if (!(w & RXE_INLINE)) continue;
+          const uint32_t t = w & RXE_TGT_MASK;
+          uint32_t np = 0;
+          for (uint32_t i = 0; i < a.size; i++) {
+            if (!entered[i]) continue;
+            const uint32_t v = a.symidx_c[(size_t)i * ncls + k];
+            bool hit = (i == t && (v & RXE_SELF)) || ((v & RXE_INLINE) && (v & RXE_TGT_MASK) == t);
+            if (!hit && (v & RXE_OVF))
+              for (uint32_t j = 0; j < a.ovf[v & RXE_TGT_MASK] && !hit; j++) hit = (a.ovf[(v & RXE_TGT_MASK) + 1 + j] & RXE_TGT_MASK) == t;
+            np += hit;
+          }
+          CHECK(((w & RXE_MAYDUP) != 0) == (np >= 2));
+        }
+    }
+    // the register kernel's index: {fast word, slice word} per (state, class), row `size` = free
+    if (!a.regidx.empty()) {
+      CHECK(a.regidx.size() == (size_t)(a.size + 1u) * ncls * 2u);
+      const bool fold = !a.pin_tab.empty();
+      for (uint32_t s = 0; s <= a.size; s += (a.size > 4000 ? 5 : 1))
+        for (uint32_t k = 0; k < ncls; k++) {
+          const uint32_t f = a.regidx[((size_t)s * ncls + k) * 2u], w = a.regidx[((size_t)s * ncls + k) * 2u + 1u];
+          CHECK(w == a.symidx_c[(size_t)s * ncls + k]);
+          const bool inl = (w & RXE_INLINE) && !(fold && (w & RXE_PIN));
+          const bool own = inl && !(w & RXE_SELF) && !(w & RXE_MAYDUP);
+          CHECK((f & RXE_TGT_MASK) == ((w & RXE_SELF) ? s : own ? (w & RXE_TGT_MASK) : a.size));
+          CHECK(((f & RXR_NEED) != 0) == ((inl && !own) || (w & RXE_OVF)));
+          CHECK(((f & RXR_ACC) != 0) == (own && (w & RXE_ACCEPT)));
+        }
+    }
+    // the folding table of the pinned state: last column = its slice without the self loop, column n = the targets of
+    // that slice that are accept states or have an edge on class n
+    if (!a.pin_tab.empty()) {
+      CHECK(a.pin_state != 0xFFFFFFFFu && a.pin_tab.size() == (size_t)ncls * (ncls + 1u));
+      auto targets = [&](uint32_t w, std::vector<uint32_t>* out) {
+        out->clear();
+        if (w & RXE_INLINE) out->push_back(w & RXE_TGT_MASK);
+        if (w & RXE_OVF) for (uint32_t j = 0; j < a.ovf[w & RXE_TGT_MASK]; j++) out->push_back(a.ovf[(w & RXE_TGT_MASK) + 1 + j] & RXE_TGT_MASK);
+      };
+      std::vector<uint32_t> full, got, want;
+      for (uint32_t k = 0; k < ncls; k++) {
+        const uint32_t w = a.symidx_c[(size_t)a.pin_state * ncls + k];
+        CHECK(w & RXE_SELF);
+        targets(w & ~RXE_SELF, &full);
+        for (uint32_t n = 0; n <= ncls; n++) {
+          targets(a.pin_tab[(size_t)k * (ncls + 1u) + n], &got);
+          want.clear();
+          for (uint32_t t : full)
+            if (n == ncls || ((a.accept_bits[t >> 5] >> (t & 31)) & 1u) || a.symidx_c[(size_t)t * ncls + n] != 0u) want.push_back(t);
+          CHECK(got == want);
+        }
+      }
+    }
     if (a.ovf_dir.empty()) { CHECK(a.symidx_p.empty()); return 0; }
     CHECK(a.symidx_p.size() == a.symidx_c.size() && a.ovf_dir.size() % (ncls + 1u) == 0);
     const uint32_t nlists = (uint32_t)(a.ovf_dir.size() / (ncls + 1u));
@@ -52,7 +114,7 @@ int main(int argc, char** argv) {
         }
         const uint32_t d = dir[k], o2 = d >> 8, c2 = (d & 255u) == 255u ? a.ovf[o2] : (d & 255u);
         CHECK(c2 == want.size());
-        for (uint32_t j = 0; j < c2; j++) CHECK(a.ovf[o2 + 1 + j] == want[j]);
+        for (uint32_t j = 0; j < c2; j++) CHECK((a.ovf[o2 + 1 + j] & ~RXE_MAYDUP) == (want[j] & ~RXE_MAYDUP));  // (lists are shared: the flag accumulates)
       }
     }
     return 0;

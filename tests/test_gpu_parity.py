@@ -385,6 +385,32 @@ def test_lazy_dfa_cache_is_persistent_and_resettable(rx, orx, automata, traces):
         check_equal(rx, orx, got, ref, "dfa")
 
 
+def test_pipelined_host_to_host_run(rx, orx, automata, traces, gpu_nfas):
+    """rx_plan_run (blocks of streams pipelined over HIP streams, page-locked caller buffers) == upload + launch +
+    download == the oracle: several blocks with events on both sides of every block boundary, one block, ragged length,
+    statistics and per-stream counters, repeated runs on one plan with the same and with a new input array."""
+    W, size = automata["snort_16"]
+    wl = rx.workloads
+    lo, hi = traces[("snort_16", "lo")], traces[("snort_16", "hi")]
+    for ns, sl, kw in ((40000, 300, dict()), (40000, 300, dict(collect_stats=True, want_match_count=True)),
+                       (9000, 517, dict(kernel=rx.KERNEL_SYM_WAVE)), (700, 1024, dict(mode=rx.MODE_TB_COMPAT)),
+                       (33000, 64, dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=32, flags=rx.host.OPT_FORCE_FOLD))):
+        rows = wl.trace_windows(lo, hi, ns, sl, first=11)
+        mode = kw.get("mode", rx.MODE_FULL)
+        ref = orx.match_batch(W, size, rows, mode=mode, want_match_count=True, events_cap=1 << 22)
+        p = rx.Plan(gpu_nfas["snort_16"], ns, sl, device=0, events_cap=1 << 21, **kw)
+        for rep in range(3):
+            data = rows if rep < 2 else rows.copy()          # same array twice (registered once), then a new one
+            got = p.run(data)
+            check_equal(rx, orx, got, ref, ("run", ns, sl, kw, rep), stats=bool(kw.get("collect_stats")))
+        p.upload(rows)                                         # the step-by-step path still works on the same plan
+        p.launch()
+        check_equal(rx, orx, p.download(), ref, ("after run", ns, sl, kw), stats=bool(kw.get("collect_stats")))
+        p.close()
+    ev = ref["events"]
+    assert len(ev) > 0
+
+
 def test_events_capacity_overflow(rx, orx, automata, traces, gpu_nfas):
     W, size = automata["snort_16"]
     rows = np.stack([traces[("snort_16", "hi")][:4000]] * 8)
