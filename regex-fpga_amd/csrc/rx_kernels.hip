@@ -37,6 +37,13 @@
 
 #include "rx_internal.hpp"
 
+// Diagnostic A/B build (make -C csrc ab -> ../librxmatch_ab.so, never shipped): the pack kernel's lanes WITHOUT a list
+// entry sit out of the filter-clear store and of the two filter atomics instead of running them as no-ops on spread-out
+// words.  Used once per round to re-measure what those extra LDS lanes cost (profiles/r02_lds_ab/).
+#ifndef RX_AB_PREDICATE_IDLE
+#define RX_AB_PREDICATE_IDLE 0
+#endif
+
 namespace {
 
 // 64-lane ballot straight from the predicate (the generic __ballot goes through an int and costs two
@@ -1040,7 +1047,7 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
       const uint32_t c = reinterpret_cast<const uint8_t*>(sreg + 2u * L::FW)[kk];  // class of that stream's input_char
       // zero the filter word this entry went through (lanes without an entry hit some word of the CURRENT filter of
       // a valid slot; that filter is being wiped this pass anyway and is not read before the next swap)
-      sreg[fcur_off + ((s & HMASK) >> 5)] = 0u;
+      if (!RX_AB_PREDICATE_IDLE || li < Ns) sreg[fcur_off + ((s & HMASK) >> 5)] = 0u;
       if (STATS && (e & E_NONE) == 0u) {
         const uint32_t deg = rp[s + 1] - rp[s];
         st_active += 1;
@@ -1087,8 +1094,9 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
       const uint32_t v0 = (x & RXE_SELF) ? 1u << (h0 & 31u) : 0u;    // bit to set, 0 = no candidate
       // (FOLD: a target that IS the folded state is dropped — the stream holds it anyway)
       const uint32_t v1 = (FOLD ? (x & (RXE_INLINE | RXE_PIN)) == RXE_INLINE : (x & RXE_INLINE) != 0u) ? 1u << (h1 & 31u) : 0u;
-      const uint32_t o0 = atomicOr(&sreg[fnext_off + (h0 >> 5)], v0);
-      const uint32_t o1 = atomicOr(&sreg[fnext_off + (h1 >> 5)], v1);
+      uint32_t o0 = 0u, o1 = 0u;
+      if (!RX_AB_PREDICATE_IDLE || v0) o0 = atomicOr(&sreg[fnext_off + (h0 >> 5)], v0);
+      if (!RX_AB_PREDICATE_IDLE || v1) o1 = atomicOr(&sreg[fnext_off + (h1 >> 5)], v1);
       __builtin_amdgcn_sched_barrier(0);  // keep the first result's consumers behind the second atomic's issue
       if (PROF) { asm volatile("" ::"v"(o0), "v"(o1)); stamp(3); }  // phase 3: the two filter atomics
       // fresh: candidate whose bit was clear; maybe: candidate whose bit was already set
