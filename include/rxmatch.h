@@ -236,13 +236,17 @@ typedef struct rx_plan rx_plan;
 int rx_plan_create(const rx_nfa* nfa, const rx_opts* opts, size_t max_streams,
                    size_t max_stream_len, size_t events_cap, uint32_t want_match_count,
                    uint32_t want_anymatch, uint32_t want_final, rx_plan** out);
-/* Copy host bytes into the plan's own HBM input buffer (row stride = stride). */
+/* Copy host bytes into the plan's own HBM input buffer (row stride = stride).  The copy is enqueued on the plan's
+ * stream: from pageable memory it has completed when the call returns, from page-locked memory (rx_host_register,
+ * hipHostMalloc) it is asynchronous — leave the buffer untouched until rx_plan_sync / rx_plan_download returns. */
 int rx_plan_upload(rx_plan* plan, const uint8_t* bytes, size_t n_streams, size_t stream_len,
                    size_t stride);
 /* Use a caller-owned DEVICE buffer as the input (e.g. a torch tensor's data_ptr). */
 int rx_plan_set_device_input(rx_plan* plan, const void* device_bytes, size_t n_streams,
                              size_t stream_len, size_t stride);
-/* Optional per-stream start state (host array, copied to HBM); NULL restores reset. */
+/* Optional per-stream start state (host array; copied — bits beyond `size` cleared — before the call returns) for the
+ * batch given last; every new input (rx_plan_upload / rx_plan_set_device_input / rx_plan_run) restores reset, and so
+ * does NULL. */
 int rx_plan_set_init_active(rx_plan* plan, const uint64_t* init_active);
 /* Enqueue result-reset + the match kernel on the plan's stream, bracketed by hipEvents. */
 int rx_plan_launch(rx_plan* plan);

@@ -406,6 +406,8 @@ int rxh_build(const uint32_t* W, size_t nwords, uint32_t size_or_0, RxHostNfa* o
           uint32_t fast = surv ? i : (own ? (w & RXE_TGT_MASK) : size);
           if (own && (w & RXE_ACCEPT)) fast |= RXR_ACC;
           if ((inl && !own) || (w & RXE_OVF)) fast |= RXR_NEED;
+          if (inl && !own) fast |= (w & RXE_MAYDUP) ? RXR_DUPC : RXR_EXTRA;  // (!own and not MAYDUP means the state survives)
+          if (w & RXE_OVF) fast |= RXR_OVFL;
           out->regidx[((size_t)i * ncls + k) * 2u] = fast;
           out->regidx[((size_t)i * ncls + k) * 2u + 1u] = w;
         }

@@ -26,8 +26,11 @@ static constexpr uint32_t RXE_PIN = 0x08000000u;   // target is the pinned state
 // is inserted.  Per-class index, overflow lists and the folding table carry the flag; kernels that deduplicate every
 // insertion through a filter ignore it, the register-resident single-stream kernel checks only flagged targets.
 static constexpr uint32_t RXE_MAYDUP = 0x04000000u;
-static constexpr uint32_t RXR_NEED = 0x80000000u;  // register kernel's fast word (RxParams::regidx)
-static constexpr uint32_t RXR_ACC = 0x40000000u;
+static constexpr uint32_t RXR_NEED = 0x80000000u;  // register kernel's fast word (RxParams::regidx): any of the three below
+static constexpr uint32_t RXR_ACC = 0x40000000u;   //   bits 23:0 name an accept state
+static constexpr uint32_t RXR_EXTRA = 0x20000000u; //   the state stays AND has one target nothing else can reach: the target needs a free lane
+static constexpr uint32_t RXR_DUPC = 0x10000000u;  //   its one target may already be in the next set (RXE_MAYDUP): check, then a free lane
+static constexpr uint32_t RXR_OVFL = 0x08000000u;  //   several targets on the byte (overflow list in the slice word)
 static constexpr uint32_t RXE_TGT_MASK = 0x00FFFFFFu;
 
 // Active-list entry (LDS): state id in bits 23:0, RXE_ACCEPT if the state is an accept state.

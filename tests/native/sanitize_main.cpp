@@ -70,6 +70,8 @@ int main(int argc, char** argv) {
           CHECK((f & RXE_TGT_MASK) == ((w & RXE_SELF) ? s : own ? (w & RXE_TGT_MASK) : a.size));
           CHECK(((f & RXR_NEED) != 0) == ((inl && !own) || (w & RXE_OVF)));
           CHECK(((f & RXR_ACC) != 0) == (own && (w & RXE_ACCEPT)));
+          CHECK(((f & RXR_EXTRA) != 0) == (inl && !own && !(w & RXE_MAYDUP)) && ((f & RXR_DUPC) != 0) == (inl && (w & RXE_MAYDUP) != 0));
+          CHECK(((f & RXR_OVFL) != 0) == ((w & RXE_OVF) != 0) && (!(f & RXR_EXTRA) || (w & RXE_SELF)));
         }
     }
     // the folding table of the pinned state: last column = its slice without the self loop, column n = the targets of

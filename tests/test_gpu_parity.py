@@ -202,6 +202,24 @@ def test_chunked_streaming_chain(rx, orx, automata, traces, gpu_nfas, kernels):
         assert np.array_equal(b["final_active"], whole["final_active"]), kern
 
 
+def test_pass_indices_up_to_the_32_bit_limit(rx, orx, automata, traces, gpu_nfas):
+    """k_base at the top of the 32-bit range: event pass indices are k_base + k exactly, no wrap; one pass more is
+    RX_EINVAL (checked before the launch)."""
+    W, size = automata["snort_16"]
+    rows = np.stack([traces[("snort_16", "hi")][:5000]] * 3)
+    ref = orx.match_batch(W, size, rows)
+    base = 2**32 - (5000 + 1)                      # FULL mode: passes 0..5000 -> the last index is 2^32 - 1
+    for kern in (dict(kernel=rx.KERNEL_AUTO), dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=13), dict(kernel=rx.KERNEL_SYM_WAVE)):
+        got = rx.match(gpu_nfas["snort_16"], rows, k_base=base, **kern)
+        want = ref["events"].astype(got["events"].dtype).copy()
+        assert int(want["k"].max()) + base < 2**32
+        want["k"] = (want["k"].astype(np.uint64) + base).astype(np.uint32)
+        assert np.array_equal(got["events"], want), kern
+        with pytest.raises(rx.RxError) as e:
+            rx.match(gpu_nfas["snort_16"], rows, k_base=base + 1, **kern)
+        assert e.value.code == -1
+
+
 def test_active_set_larger_than_list_capacity(rx, orx, kernels):
     """|S_k| = 300 > RX_LIST_CAP: the dense (bitmask-walk) form must give identical results."""
     W, size = blowup_nfa(300)

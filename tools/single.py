@@ -17,7 +17,7 @@ ns = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 H = rx.host
 for name, trace in (("hi", hi), ("lo", lo)):
     rows = np.stack([trace[:200000]] * ns)
-    for label, kw in (("auto", dict(kernel=rx.KERNEL_AUTO)), ("reg+fold", dict(kernel=rx.KERNEL_SYM_REG)),
+    for label, kw in (("auto", dict(kernel=rx.KERNEL_AUTO)), ("reg+fold", dict(kernel=rx.KERNEL_SYM_REG, flags=H.OPT_VERBOSE)),
                       ("reg", dict(kernel=rx.KERNEL_SYM_REG, flags=H.OPT_NO_FOLD | H.OPT_VERBOSE)),
                       ("pack16", dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=16)),
                       ("pack8+fold", dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=8, flags=H.OPT_FORCE_FOLD)),
