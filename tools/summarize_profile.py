@@ -51,8 +51,11 @@ def main():
         pmc["salu_issue_frac"] = round(c["SQ_INSTS_SALU"]["mean_per_launch"] / (256 * clk * t_s), 4)
     if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
         pmc["wave_cycles_waiting_frac"] = round(c["SQ_WAIT_ANY"]["mean_per_launch"] / c["SQ_WAVE_CYCLES"]["mean_per_launch"], 4)
-    if "SQ_LDS_BANK_CONFLICT" in c and "SQ_ACTIVE_INST_LDS" in c:
-        pmc["lds_conflict_cycles_per_lds_active_cycle"] = round(c["SQ_LDS_BANK_CONFLICT"]["mean_per_launch"] / c["SQ_ACTIVE_INST_LDS"]["mean_per_launch"], 4)
+    # (SQ_LDS_BANK_CONFLICT and SQ_LDS_IDX_ACTIVE count LDS-array cycles; SQ_ACTIVE_INST_LDS counts quad-cycles of waves
+    # and must not be the denominator — profiles/r02_lds_ab/README.md)
+    if "SQ_LDS_BANK_CONFLICT" in c and "SQ_LDS_IDX_ACTIVE" in c:
+        pmc["lds_conflict_frac_of_lds_array_cycles"] = round(c["SQ_LDS_BANK_CONFLICT"]["mean_per_launch"] / c["SQ_LDS_IDX_ACTIVE"]["mean_per_launch"], 4)
+        pmc["lds_array_utilisation"] = round(c["SQ_LDS_IDX_ACTIVE"]["mean_per_launch"] / (256 * clk * t_s), 4)
     if "TCP_TCC_READ_REQ_sum" in c and "SQ_INSTS_VMEM_RD" in c:
         pmc["l2_requests_per_vmem_read_instruction"] = round(c["TCP_TCC_READ_REQ_sum"]["mean_per_launch"] / c["SQ_INSTS_VMEM_RD"]["mean_per_launch"], 3)
     if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
