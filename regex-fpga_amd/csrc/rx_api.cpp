@@ -251,10 +251,8 @@ static int get_dev_tables(const rx_nfa* cnfa, int device, DevTables* out) {
   if ((rc = upload_vec(nfa->h.ovf, &t.ovf))) return rc;
   if ((rc = upload_vec(nfa->h.accept_bits, &t.accept_bits))) return rc;
   if ((rc = upload_vec(nfa->h.symidx_c, &t.symidx_c))) return rc;
-  if (!nfa->h.ovf_dir.empty()) {
-    if ((rc = upload_vec(nfa->h.symidx_p, &t.symidx_p))) return rc;
-    if ((rc = upload_vec(nfa->h.ovf_dir, &t.ovf_dir))) return rc;
-  }
+  if (!nfa->h.symidx_p.empty() && (rc = upload_vec(nfa->h.symidx_p, &t.symidx_p))) return rc;
+  if (!nfa->h.ovf_dir.empty() && (rc = upload_vec(nfa->h.ovf_dir, &t.ovf_dir))) return rc;
   if (!nfa->h.pin_tab.empty() && (rc = upload_vec(nfa->h.pin_tab, &t.pin_tab))) return rc;
   if (!nfa->h.regidx.empty() && (rc = upload_vec(nfa->h.regidx, &t.regidx))) return rc;
   {
@@ -615,6 +613,7 @@ static void fill_common(rx_plan* p, RxParams& a) {
   a.accept_bits = p->tab.accept_bits;
   a.symidx_c = p->tab.symidx_c;
   a.symidx_p = p->tab.symidx_p;
+  a.prune_narrow = h.prune_narrow ? 1u : 0u;
   a.ovf_dir = p->tab.ovf_dir;
   a.byte_class = p->tab.byte_class;
   a.pin_tab = p->tab.pin_tab;
@@ -719,6 +718,13 @@ static int auto_probe(rx_plan* p) {
   // (pruning must remove at least a tenth of the entries to pay for its directory look-ups: l7-filter meets
   // multi-target rows in every pass but nearly all of their targets live on)
   p->probe_prune = p->tab.ovf_dir && (double)cnt[5] / own >= 0.02 && (double)cnt[6] / own >= 0.10;
+  // (With the narrow pruned index the PRUNE build also drops INLINE targets that die on the next byte — -21 % list entries
+  // on the snort_16 trace windows.  Measured this round it does not pay on its own: the PRUNE pass reads a second class
+  // byte and carries the look-ahead layout, and costs more than the entries it saves at every batch size — 65 536
+  // streams 1.09 vs 1.05 ms, 262 144 streams 4.09 vs 3.90 ms.  So the trigger stays the multi-target statistic above;
+  // where PRUNE runs for that reason, the inline targets are pruned along.)
+  const double dead_frac = (double)cnt[6] / own;  // (the runs below overwrite cnt[])
+  const double left_pruned = active;
   // Always-on-state folding (automata whose state 0 enters a `.*` state on every byte): that state leaves the lists, and
   // of its targets only those that survive the next byte enter them.  The FOLD build pays a fixed price per pass for
   // the folded state's table look-ups and wins when the lists are nearly empty afterwards (measured, snort_16, one
@@ -741,7 +747,7 @@ static int auto_probe(rx_plan* p) {
     if (left <= 0.3 && spilled <= 0.02) { p->auto_lanes = lanes; p->auto_fold = true; p->auto_prune = prune; return RX_OK; }
   }
   if (p->probe_prune && !(p->opts.flags & RX_OPT_NO_PRUNE)) {
-    const double entries = active * (1.0 - (double)cnt[6] / own);
+    const double entries = std::min(active * (1.0 - dead_frac), left_pruned);
     if (entries <= 6.0) {
       const uint32_t lanes = lanes_for(entries);
       if ((rc = run(lanes, false, true, &spilled))) return rc;
@@ -796,7 +802,7 @@ static int prepare_launch(rx_plan* p) {
   if (kernel == RX_KERNEL_AUTO && p->n_streams <= 4 && p->opts.collect_stats == 0 && !p->have_init && p->tab.regidx)
     kernel = RX_KERNEL_SYM_REG;
   // the probe also serves an explicit RX_KERNEL_SYM_PACK: whether look-ahead pruning pays depends on the input
-  const bool probe_for_pack = kernel == RX_KERNEL_SYM_PACK && p->tab.ovf_dir && p->opts.collect_stats == 0;
+  const bool probe_for_pack = kernel == RX_KERNEL_SYM_PACK && p->tab.symidx_p && p->opts.collect_stats == 0;
   if ((kernel == RX_KERNEL_AUTO || probe_for_pack) && !pair && !p->have_init) {
     if (!p->auto_decided) {
       if ((rc = auto_probe(p))) return rc;
@@ -839,7 +845,7 @@ static int prepare_launch(rx_plan* p) {
   // look-ahead pruning of multi-target rows follows the probe: AUTO's verified choice, or for an explicit
   // RX_KERNEL_SYM_PACK what the probe's statistics say.  rx_opts.flags RX_OPT_NO_PRUNE / RX_OPT_FORCE_PRUNE override it
   // (A/B measurements; tests, whose batches are too small for a probe).
-  p->cfg.prune = p->tab.ovf_dir != nullptr && !(p->opts.flags & RX_OPT_NO_PRUNE) &&
+  p->cfg.prune = p->tab.symidx_p != nullptr && !(p->opts.flags & RX_OPT_NO_PRUNE) &&
                  ((p->opts.flags & RX_OPT_FORCE_PRUNE) != 0 ||
                   (p->opts.kernel == RX_KERNEL_SYM_PACK ? p->probe_prune : p->opts.kernel == RX_KERNEL_AUTO && p->auto_prune));
   const bool two_tier = p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK ||
@@ -1027,7 +1033,7 @@ static int plan_download(rx_plan* p, rx_result* res) {
   st.kernel_used = p->cfg.kernel;
   st.lanes_used = (p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK) ? p->cfg.group_lanes : 0u;
   st.variant = (p->cfg.stats ? RX_VARIANT_STATS : 0u) |
-               (p->cfg.kernel == RX_KERNEL_SYM_PACK && p->cfg.prune && !p->cfg.stats && p->tab.ovf_dir ? RX_VARIANT_PRUNE : 0u) |
+               (p->cfg.kernel == RX_KERNEL_SYM_PACK && p->cfg.prune && !p->cfg.stats && p->tab.symidx_p ? RX_VARIANT_PRUNE : 0u) |
                (p->cfg.fold ? RX_VARIANT_FOLD : 0u);
   st.n_launches = (p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK ||
                    p->cfg.kernel == RX_KERNEL_DFA || p->cfg.kernel == RX_KERNEL_SYM_REG) ? 2 : 1;
@@ -1245,7 +1251,7 @@ static int plan_run(rx_plan* p, const uint8_t* bytes, size_t n_streams, size_t s
   st.kernel_used = p->cfg.kernel;
   st.lanes_used = (p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK) ? p->cfg.group_lanes : 0u;
   st.variant = (p->cfg.stats ? RX_VARIANT_STATS : 0u) |
-               (p->cfg.kernel == RX_KERNEL_SYM_PACK && p->cfg.prune && !p->cfg.stats && p->tab.ovf_dir ? RX_VARIANT_PRUNE : 0u) |
+               (p->cfg.kernel == RX_KERNEL_SYM_PACK && p->cfg.prune && !p->cfg.stats && p->tab.symidx_p ? RX_VARIANT_PRUNE : 0u) |
                (p->cfg.fold ? RX_VARIANT_FOLD : 0u);
   res->n_events = 0;
   res->events_overflow = 0;

@@ -271,12 +271,27 @@ int rxh_build(const uint32_t* W, size_t nwords, uint32_t size_or_0, RxHostNfa* o
         if (!ok) break;
       }
     }
-    if (ok) {
+    if (!ok) out->ovf_dir.clear();
+    // The pruned index exists when the directory does, or when there is nothing to put in a directory.  "Narrow" automata
+    // (state ids and list numbers fit 16 bits) also get the INLINE targets' next-class bits: bit (n & 7) of bits 23:16 is
+    // set iff the target has an edge on some class n' with n' & 7 == n & 7 (conservative: a set bit only means "may
+    // live"), all ones for an accept state — what look-ahead pruning does for multi-target rows, for single targets.
+    out->prune_narrow = false;
+    if (ok || n == 0) {
       out->symidx_p = out->symidx_c;
       for (uint32_t& w : out->symidx_p)
         if (w & RXE_OVF) w = (w & ~RXE_TGT_MASK) | list_no[w & RXE_TGT_MASK];
-    } else {
-      out->ovf_dir.clear();
+      if (size <= 65536u && n <= 65536u) {
+        out->prune_narrow = true;
+        std::vector<uint8_t> live8(size, 0);
+        for (uint32_t t = 0; t < size; t++) {
+          if (is_acc(t)) { live8[t] = 0xFF; continue; }
+          for (uint32_t k = 0; k < ncls; k++)
+            if (out->symidx_c[(size_t)t * ncls + k] != 0u) live8[t] |= (uint8_t)(1u << (k & 7u));
+        }
+        for (uint32_t& w : out->symidx_p)
+          if (w & RXE_INLINE) w |= (uint32_t)live8[w & 0xFFFFu] << 16;
+      }
     }
   }
   // ---- always-on-state folding (pack kernel FOLD builds) ----------------------------------------------------------
@@ -364,14 +379,14 @@ int rxh_build(const uint32_t* W, size_t nwords, uint32_t size_or_0, RxHostNfa* o
       for (uint32_t j = 0; j < out->ovf[off]; j++)
         if (dup(out->ovf[off + 1u + j] & RXE_TGT_MASK, k)) out->ovf[off + 1u + j] |= RXE_MAYDUP;
     };
-    const bool have_dir = !out->ovf_dir.empty();
+    const bool have_dir = !out->ovf_dir.empty(), have_p = !out->symidx_p.empty();
     for (uint32_t i = 0; i < size; i++)
       for (uint32_t k = 0; k < ncls; k++) {
         const size_t at = (size_t)i * ncls + k;
         const uint32_t w = out->symidx_c[at];
         if ((w & RXE_INLINE) && dup(w & RXE_TGT_MASK, k)) {
           out->symidx_c[at] |= RXE_MAYDUP;
-          if (have_dir) out->symidx_p[at] |= RXE_MAYDUP;
+          if (have_p) out->symidx_p[at] |= RXE_MAYDUP;
         }
         if (w & RXE_OVF) {
           flag_list(w & RXE_TGT_MASK, k);
@@ -384,7 +399,7 @@ int rxh_build(const uint32_t* W, size_t nwords, uint32_t size_or_0, RxHostNfa* o
       }
     // one all-zero row behind the per-class index: the id `size` is the register kernel's "free lane" (rx_kernels.hip)
     out->symidx_c.resize((size_t)(size + 1u) * ncls, 0u);
-    if (have_dir) out->symidx_p.resize((size_t)(size + 1u) * ncls, 0u);
+    if (have_p) out->symidx_p.resize((size_t)(size + 1u) * ncls, 0u);
     if (!out->pin_tab.empty())
       for (uint32_t k = 0; k < ncls; k++)
         for (uint32_t n = 0; n <= ncls; n++) {

@@ -50,8 +50,12 @@ struct RxParams {
   // look-ahead pruning of multi-target rows (pack kernel, see rx_host.cpp): index whose RXE_OVF payload is a LIST
   // NUMBER, and per list (n_classes + 1) directory words (ovf offset << 8 | min(count, 255)): entry c = the targets
   // that survive a next byte of class c, entry n_classes = the full list.  Both null when there is nothing to prune.
+  // prune_narrow = 1 (automata with <= 65 536 states and lists): symidx_p keeps target / list number in bits 15:0 and, for an
+  // inline target, bits 23:16 = which byte classes (mod 8) the TARGET has an edge on (all ones for an accept state): an
+  // inline target whose bit for the stream's next byte is clear dies at once and is not inserted either.
   const uint32_t* symidx_p;
   const uint32_t* ovf_dir;
+  uint32_t prune_narrow;
   // always-on-state folding (pack kernel FOLD builds, see rx_host.cpp): what the pinned `.*` state's row emits on a byte
   // of class c when the stream's next byte has class n — pin_tab[c * pin_cols + n], column n_classes = no look-ahead (the
   // full slice).  Entry: 0 | RXE_INLINE|target[|RXE_ACCEPT] | RXE_OVF|offset into `ovf`.  Null when the automaton has no
@@ -161,6 +165,7 @@ struct RxHostNfa {
   uint32_t pin_state = 0xFFFFFFFFu;
   // look-ahead pruning tables (RxParams::symidx_p / ovf_dir); empty when the automaton has no multi-target rows
   std::vector<uint32_t> symidx_p, ovf_dir;
+  bool prune_narrow = false;  // symidx_p carries the inline targets' next-class bits (RxParams::prune_narrow)
   // folding table of the pinned state (RxParams::pin_tab), n_classes * (n_classes + 1) words; empty unless state 0
   // enters the pinned state on every byte (then every stream that starts from reset holds it from pass 1 on)
   std::vector<uint32_t> pin_tab;

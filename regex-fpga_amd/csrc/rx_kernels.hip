@@ -844,6 +844,9 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
   const uint32_t* __restrict__ rp = p.words;
   constexpr bool prune = PRUNE;
   const uint32_t* __restrict__ symidx = PRUNE ? p.symidx_p : p.symidx_c;
+  // PRUNE, narrow index: target / list number in bits 15:0 of a slice word, the inline target's next-class bits above
+  const bool narrow = PRUNE && p.prune_narrow != 0u;
+  const uint32_t xtmask = narrow ? 0xFFFFu : RXE_TGT_MASK;
   const uint32_t ncls = p.n_classes;
   const uint32_t* __restrict__ ovf = p.ovf;
   unsigned long long st_active = 0, st_edges = 0, st_cost = 0, st_ovf = 0, st_dead = 0, fold_entries = 0;
@@ -991,6 +994,8 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
     // state's row emits on this byte, already reduced to the targets that survive the NEXT byte (full slice at the
     // stream's last byte, whose sets are reported).  Two dependent LDS reads that do not depend on the list: they are
     // in flight while the sweep below reads its entries, and the insertion (part 2) runs in the shadow of the gather.
+    // PRUNE: bits 23:16 forced to ones where inline targets are not to be pruned (wide index; the stream's last byte)
+    const uint32_t keep_all = (PRUNE && narrow && k + 1u < p.n_consume) ? 0u : 0x00FF0000u;
     uint32_t vA = 0u;
     const bool pin_now = FOLD && consume && k >= 1u;  // wave-uniform
     if (pin_now && owner) {
@@ -1024,7 +1029,7 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
     // several flags reaches __ballot through a VGPR (v_cndmask + v_cmp), and this loop is bound by instruction issue.
     constexpr uint32_t E_NONE = 0x80000000u;  // list-entry flag of a lane without an entry (bit 31 is otherwise unused)
     const uint32_t Ns = (uint32_t)__builtin_amdgcn_readfirstlane((int)N);  // wave-uniform: keep the loop scalar
-    if (FOLD && consume) fold_entries += Ns;  // (scalar) what AUTO's probe reads: list entries left per stream-byte
+    if ((FOLD || PRUNE) && consume) fold_entries += Ns;  // (scalar) what AUTO's probe reads: list entries left per stream-byte
     for (uint32_t b0 = 0; b0 < Ns; b0 += 64u) {
       const uint32_t li = b0 + lane;
       uint32_t e = clist[li];  // lanes past N read harmless LDS words of this wave and are overwritten below
@@ -1045,6 +1050,8 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
       if (!consume) continue;
       const bool live = (e & (E_NONE | RXE_ACCEPT)) == 0u;  // a real entry that is not an accept state: it has a row
       const uint32_t c = reinterpret_cast<const uint8_t*>(sreg + 2u * L::FW)[kk];  // class of that stream's input_char
+      uint32_t cnx = 0u;  // PRUNE: class of its NEXT byte (byte 64 of the window: the stash)
+      if (PRUNE) cnx = reinterpret_cast<const uint8_t*>(sreg + 2u * L::FW)[kk + 1u];
       // zero the filter word this entry went through (lanes without an entry hit some word of the CURRENT filter of
       // a valid slot; that filter is being wiped this pass anyway and is not read before the next swap)
       if (!RX_AB_PREDICATE_IDLE || li < Ns) sreg[fcur_off + ((s & HMASK) >> 5)] = 0u;
@@ -1089,11 +1096,16 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
       // by every lane, back to back, with one wait: a lane without a candidate ORs 0 (a no-op) into the word its
       // hash names anyway instead of sitting out in a branch or selecting another address.
       constexpr uint32_t T1_MASK = RXE_TGT_MASK | RXE_ACCEPT;
-      const uint32_t t1 = (x & T1_MASK) | (e_keep & ~T1_MASK);  // v_bfi: a live e has only its slot bits outside the mask
+      const uint32_t t1 = PRUNE ? (x & (xtmask | RXE_ACCEPT)) | (e_keep & ~T1_MASK)
+                                : (x & T1_MASK) | (e_keep & ~T1_MASK);  // v_bfi: a live e has only its slot bits outside the mask
       const uint32_t h0 = e & HMASK, h1 = x & HMASK;
       const uint32_t v0 = (x & RXE_SELF) ? 1u << (h0 & 31u) : 0u;    // bit to set, 0 = no candidate
       // (FOLD: a target that IS the folded state is dropped — the stream holds it anyway)
-      const uint32_t v1 = (FOLD ? (x & (RXE_INLINE | RXE_PIN)) == RXE_INLINE : (x & RXE_INLINE) != 0u) ? 1u << (h1 & 31u) : 0u;
+      // (PRUNE, narrow index: an inline target that is no accept state and has no edge on the stream's next byte can neither
+      // pulse nor produce a successor: it is not inserted — except at the stream's last byte, whose sets are reported)
+      bool inl = FOLD ? (x & (RXE_INLINE | RXE_PIN)) == RXE_INLINE : (x & RXE_INLINE) != 0u;
+      if (PRUNE) inl = inl && (((x | keep_all) >> (16u + (cnx & 7u))) & 1u) != 0u;
+      const uint32_t v1 = inl ? 1u << (h1 & 31u) : 0u;
       uint32_t o0 = 0u, o1 = 0u;
       if (!RX_AB_PREDICATE_IDLE || v0) o0 = atomicOr(&sreg[fnext_off + (h0 >> 5)], v0);
       if (!RX_AB_PREDICATE_IDLE || v1) o1 = atomicOr(&sreg[fnext_off + (h1 >> 5)], v1);
@@ -1123,7 +1135,7 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
           // ones reported (the stream's last byte)
           uint32_t sel = ncls;
           if (k + 1u < p.n_consume) sel = reinterpret_cast<const uint8_t*>(sreg + 2u * L::FW)[kk + 1u];  // byte 64: stash
-          const uint32_t d = (x & RXE_OVF) ? p.ovf_dir[(x & RXE_TGT_MASK) * (ncls + 1u) + sel] : 0u;
+          const uint32_t d = (x & RXE_OVF) ? p.ovf_dir[(x & xtmask) * (ncls + 1u) + sel] : 0u;
           myoff = d >> 8;
           mycnt = d & 255u;
           if (mycnt == 255u) mycnt = ovf[myoff];
@@ -1234,7 +1246,7 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
   if (!spilled && p.anymatch && (k & 31u) != 0u) store_anymatch(k >> 5);
   if (PROF && lane == 0)
     for (int q = 0; q < 7; q++) atomicAdd(&p.counters[8 + q], t_sum[q]);
-  if (FOLD && lane == 0 && fold_entries) atomicAdd(&p.counters[7], fold_entries);
+  if ((FOLD || PRUNE) && lane == 0 && fold_entries) atomicAdd(&p.counters[7], fold_entries);
   // final active sets: the rows were zeroed at the start of this kernel; set the listed bits
   if (p.final_active && !spilled) {
     for (uint32_t li = lane; li < N; li += 64u) {
@@ -1837,7 +1849,7 @@ static int launch_pack_as(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t
 
 template <int S>
 static int launch_pack(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s) {
-  if (cfg.prune && !cfg.stats && p.ovf_dir) return launch_pack_as<S, true>(p, cfg, s);
+  if (cfg.prune && !cfg.stats && p.symidx_p) return launch_pack_as<S, true>(p, cfg, s);
   return launch_pack_as<S, false>(p, cfg, s);
 }
 
@@ -1845,7 +1857,7 @@ static int launch_pack(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s)
 // wavefronts); never with statistics.
 template <int S>
 static int launch_fold(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s, size_t lds_per_cu) {
-  const bool prune = cfg.prune && p.ovf_dir;
+  const bool prune = cfg.prune && p.symidx_p;
   const uint32_t ww = prune ? PackLayout<S, true, true>::WAVE_WORDS : PackLayout<S, false, true>::WAVE_WORDS;
   const uint32_t fixed = PackLayout<S, false, true>::CMAPW + p.n_classes * p.pin_cols;
   const uint32_t waves = (p.n_streams + S - 1) / S;

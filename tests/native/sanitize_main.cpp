@@ -97,12 +97,25 @@ int main(int argc, char** argv) {
         }
       }
     }
-    if (a.ovf_dir.empty()) { CHECK(a.symidx_p.empty()); return 0; }
+    // the pruned index: absent, or the per-class index with list numbers for offsets and — narrow form — the inline
+    // targets' next-class bits in bits 23:16 (bit b set iff the target is an accept state or has an edge on a class = b mod 8)
+    if (a.symidx_p.empty()) { CHECK(a.ovf_dir.empty()); return 0; }
     CHECK(a.symidx_p.size() == a.symidx_c.size() && a.ovf_dir.size() % (ncls + 1u) == 0);
     const uint32_t nlists = (uint32_t)(a.ovf_dir.size() / (ncls + 1u));
+    if (a.prune_narrow) CHECK(a.size <= 65536u && nlists <= 65536u);
     for (size_t i = 0; i < a.symidx_c.size(); i++) {
       const uint32_t w = a.symidx_c[i], q = a.symidx_p[i];
-      if (!(w & RXE_OVF)) { CHECK(q == w); continue; }
+      if (!(w & RXE_OVF)) {
+        if (a.prune_narrow && (w & RXE_INLINE)) {
+          const uint32_t t = w & RXE_TGT_MASK;
+          uint32_t live = ((a.accept_bits[t >> 5] >> (t & 31)) & 1u) ? 0xFFu : 0u;
+          for (uint32_t k = 0; k < ncls; k++) if (a.symidx_c[(size_t)t * ncls + k] != 0u) live |= 1u << (k & 7u);
+          CHECK(q == (w | (live << 16)));
+        } else {
+          CHECK(q == w);
+        }
+        continue;
+      }
       CHECK((q & ~RXE_TGT_MASK) == (w & ~RXE_TGT_MASK) && (q & RXE_TGT_MASK) < nlists);
       const uint32_t* dir = &a.ovf_dir[(size_t)(q & RXE_TGT_MASK) * (ncls + 1u)];
       const uint32_t off = w & RXE_TGT_MASK, cnt = a.ovf[off];
