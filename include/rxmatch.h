@@ -139,6 +139,12 @@ enum {
                              (testbench_BLK_Mem.sv:49-87).  RX_KERNEL_AUTO picks it for up to 4 streams from reset;
                              more than 64 active states: hand-off to RX_KERNEL_SYM_WAVE.  With collect_stats or a
                              caller-supplied start set RX_KERNEL_SYM_WAVE runs instead.                      */
+  ,
+  RX_KERNEL_SYM_RPACK = 7 /* the register kernel's recipe for MANY streams: S streams per wavefront (rx_opts.group_lanes =
+                             8/16/24/32, default 16) share the 64 lanes as entry slots, in-place precomputed updates, the
+                             `.*` state folded out, one vectorised placement per pass for what needs a lane of its own.
+                             Needs an automaton whose state 0 enters a `.*` state on every byte (else, and with
+                             collect_stats or a start set, RX_KERNEL_SYM_PACK / RX_KERNEL_SYM_WAVE run instead).  */
 };
 
 typedef struct rx_opts {
