@@ -618,6 +618,7 @@ static void fill_common(rx_plan* p, RxParams& a) {
   a.byte_class = p->tab.byte_class;
   a.pin_tab = p->tab.pin_tab;
   a.regidx = p->tab.regidx;
+  a.reg_tmask = h.reg_tmask;
   a.pin_cols = h.n_classes + 1u;
   a.n_classes = h.n_classes;
   a.size = h.size;

@@ -409,8 +409,20 @@ int rxh_build(const uint32_t* W, size_t nwords, uint32_t size_or_0, RxHostNfa* o
         }
     // ---- the register kernel's index: the in-place update of a lane precomputed per (state, class) ------------------
     out->regidx.clear();
+    out->reg_tmask = RXE_TGT_MASK;
     if ((uint64_t)(size + 1u) * ncls * 8u <= ((uint64_t)256 << 20)) {
       const bool fold = !out->pin_tab.empty();
+      const bool narrow = size < 65536u;
+      std::vector<uint8_t> live8;  // which byte classes (mod 8) a state has an edge on; accept states: all
+      if (narrow) {
+        out->reg_tmask = 0xFFFFu;
+        live8.assign(size, 0);
+        for (uint32_t t = 0; t < size; t++) {
+          if (is_acc(t)) { live8[t] = 0xFF; continue; }
+          for (uint32_t k = 0; k < ncls; k++)
+            if (out->symidx_c[(size_t)t * ncls + k] != 0u) live8[t] |= (uint8_t)(1u << (k & 7u));
+        }
+      }
       out->regidx.assign((size_t)(size + 1u) * ncls * 2u, 0u);
       for (uint32_t i = 0; i <= size; i++)
         for (uint32_t k = 0; k < ncls; k++) {
@@ -423,6 +435,7 @@ int rxh_build(const uint32_t* W, size_t nwords, uint32_t size_or_0, RxHostNfa* o
           if ((inl && !own) || (w & RXE_OVF)) fast |= RXR_NEED;
           if (inl && !own) fast |= (w & RXE_MAYDUP) ? RXR_DUPC : RXR_EXTRA;  // (!own and not MAYDUP means the state survives)
           if (w & RXE_OVF) fast |= RXR_OVFL;
+          if (narrow && (fast & RXR_NEED)) fast |= (uint32_t)((w & RXE_OVF) ? 0xFFu : live8[w & RXE_TGT_MASK]) << 16;
           out->regidx[((size_t)i * ncls + k) * 2u] = fast;
           out->regidx[((size_t)i * ncls + k) * 2u + 1u] = w;
         }

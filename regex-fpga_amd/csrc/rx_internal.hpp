@@ -66,7 +66,12 @@ struct RxParams {
   // holds after the byte (the state itself if it loops, its one target if nothing else can reach that, else the id
   // `size` = free), RXR_NEED = something needs a lane of its own (see rx_sym_reg_kernel), RXR_ACC = bits 23:0 name an
   // accept state.  Row `size` is all {size, 0}.  Built with the folded state's targets dropped iff pin_tab exists.
+  // reg_tmask = 0xFFFF (automata with < 65 536 states): the value is in bits 15:0 and bits 23:16 say for which NEXT byte
+  // the need is real — bit (n & 7) set iff the single target that wants a lane has an edge on some class n' with
+  // n' & 7 == n & 7 (all ones: accept state, or several targets) — one byte of look-ahead for single targets, as the
+  // folding table has it for the folded state's.  reg_tmask = 0xFFFFFF otherwise (bits 23:0 value, no look-ahead).
   const uint32_t* regidx;
+  uint32_t reg_tmask;
   const uint32_t* byte_class;   // [64] words = 256 bytes: class id of every input byte
   uint32_t n_classes;
   const uint32_t* ovf;          // overflow target lists of the slice index
@@ -171,6 +176,7 @@ struct RxHostNfa {
   std::vector<uint32_t> pin_tab;
   // RxParams::regidx; empty for automata whose table would exceed 256 MB (the register kernel is then not offered)
   std::vector<uint32_t> regidx;
+  uint32_t reg_tmask = RXE_TGT_MASK;  // RxParams::reg_tmask
   const uint32_t* row_ptr() const { return words.data(); }
   const uint32_t* col() const { return words.data() + size + 1; }
 };

@@ -1623,10 +1623,10 @@ __global__ void __launch_bounds__(64) rx_sym_reg_kernel(const RxParams p) {
     return *reinterpret_cast<const uint2*>(regidx + (__umul24(e, ncls8) + (c << 3)));
   };
   // the rare part of a pass: everything that needs a lane of its own.  xs = slice words, e_in = S_k (for the hand-off).
-  auto slow = [&](uint32_t k, uint32_t xs, uint32_t e_in, uint32_t vA) {
+  auto slow = [&](uint32_t k, uint32_t xs, bool kept, uint32_t e_in, uint32_t vA) {
     const bool surv = (xs & RXE_SELF) != 0u;
     const bool inl = FOLD ? (xs & (RXE_INLINE | RXE_PIN)) == RXE_INLINE : (xs & RXE_INLINE) != 0u;
-    uint64_t mx = wballot(inl && (surv || (xs & RXE_MAYDUP)));  // (an in-place target is neither)
+    uint64_t mx = wballot(inl && kept && (surv || (xs & RXE_MAYDUP)));  // (an in-place target is neither)
     uint64_t mo = wballot(xs & RXE_OVF);
     uint64_t mfree = wballot(e == FREE);
     bool full = false;
@@ -1683,19 +1683,24 @@ __global__ void __launch_bounds__(64) rx_sym_reg_kernel(const RxParams p) {
   };
 
   uint2 x = n_consume ? gather(bcast(cwn, 0) & 0xFFu) : make_uint2(0u, 0u);  // the words for pass 0 are in flight
-  // One byte-consuming pass.  cn = class of the NEXT byte (scalar), vA = the folded state's emission in this pass.
-  auto pass = [&](uint32_t k, uint32_t cn, uint32_t vA) {
+  // One byte-consuming pass.  cn = class of the NEXT byte (scalar), vA = the folded state's emission in this pass,
+  // look = the next byte will be consumed too (a single target with no edge on it need not be placed; the set after
+  // the stream's last byte is reported and gets everything).
+  const uint32_t tmask = p.reg_tmask;
+  const uint32_t nm_base = tmask == 0xFFFFu ? 0x10000u : RXR_NEED, nm_and = tmask == 0xFFFFu ? 7u : 0u;
+  auto pass = [&](uint32_t k, uint32_t cn, uint32_t vA, bool look) {
     if (__builtin_expect(macc != 0ull, 0)) pulses(k);
     const uint32_t xf = x.x, xs = x.y, e_in = e;
-    e = xf & RXE_TGT_MASK;                          // every lane's in-place update, precomputed
-    const uint64_t need = wballot((int)xf < 0);     // RXR_NEED
+    e = xf & tmask;                                 // every lane's in-place update, precomputed
+    const uint32_t nm = look ? nm_base << (cn & nm_and) : RXR_NEED;
+    const uint64_t need = wballot(xf & nm);         // RXR_NEED, or its look-ahead bit for the next byte's class
     if (__builtin_expect(need == 0ull && vA == 0u, 1)) {
       x = gather(cn);                                // the dependency chain of the stream ends here: gather k+1 is out
       __builtin_amdgcn_sched_barrier(0);
       macc = wballot(xf & RXR_ACC);                  // built while the gather is in flight
     } else {
       macc = wballot(xf & RXR_ACC);
-      slow(k, xs, e_in, vA);
+      slow(k, xs, (xf & nm) != 0u, e_in, vA);
       x = gather(cn);
     }
   };
@@ -1719,28 +1724,32 @@ __global__ void __launch_bounds__(64) rx_sym_reg_kernel(const RxParams p) {
       }
     }
     const uint32_t kchunk = n_consume - k < 256u ? n_consume : k + 256u;
-    while (k + 4u <= kchunk && !handed_off) {  // four passes on the classes of one SGPR pair, no per-pass loop tests
+    // four passes on the classes of one SGPR pair, no per-pass loop tests; never the stream's last pass
+    while (k + 4u <= kchunk && k + 4u < n_consume && !handed_off) {
       const uint32_t gi = (k >> 2) & 63u;
       const uint32_t c4 = bcast(cw, gi);
       const uint32_t c4n = gi == 63u ? bcast(cwn, 0) : bcast(cw, gi + 1u);
-      pass(k, (c4 >> 8) & 0xFFu, FOLD ? bcast(va[0], gi) : 0u);
+      pass(k, (c4 >> 8) & 0xFFu, FOLD ? bcast(va[0], gi) : 0u, true);
       if (__builtin_expect(handed_off, 0)) break;
-      pass(k + 1u, (c4 >> 16) & 0xFFu, FOLD ? bcast(va[1], gi) : 0u);
+      pass(k + 1u, (c4 >> 16) & 0xFFu, FOLD ? bcast(va[1], gi) : 0u, true);
       if (__builtin_expect(handed_off, 0)) break;
-      pass(k + 2u, c4 >> 24, FOLD ? bcast(va[2], gi) : 0u);
+      pass(k + 2u, c4 >> 24, FOLD ? bcast(va[2], gi) : 0u, true);
       if (__builtin_expect(handed_off, 0)) break;
-      pass(k + 3u, c4n & 0xFFu, FOLD ? bcast(va[3], gi) : 0u);
+      pass(k + 3u, c4n & 0xFFu, FOLD ? bcast(va[3], gi) : 0u, true);
       if (__builtin_expect(handed_off, 0)) break;
       k += 4u;
       if (p.anymatch && (k & 31u) == 0u) store_anymatch(k - 1u);
     }
-    while (k < kchunk && !handed_off) {  // the last one to three passes of the stream
+    while (k < kchunk && !handed_off) {  // the last passes of the stream (or of a chunk that ends with it)
       const uint32_t gi = (k >> 2) & 63u, q = k & 3u;
       const uint32_t c4 = bcast(cw, gi);
+      const uint32_t c4n = gi == 63u ? bcast(cwn, 0) : bcast(cw, gi + 1u);
       const uint32_t vq = q == 0u ? va[0] : (q == 1u ? va[1] : (q == 2u ? va[2] : va[3]));
-      pass(k, (c4 >> (8u * ((q + 1u) & 3u))) & 0xFFu, FOLD ? bcast(vq, gi) : 0u);  // (the look-ahead class is not used at the last byte)
+      const uint32_t cn = q == 3u ? c4n & 0xFFu : (c4 >> (8u * q + 8u)) & 0xFFu;
+      pass(k, cn, FOLD ? bcast(vq, gi) : 0u, k + 1u < n_consume);
       if (handed_off) break;
       k++;
+      if (p.anymatch && (k & 31u) == 0u) store_anymatch(k - 1u);
     }
   }
   if (!handed_off) {
@@ -1792,6 +1801,7 @@ template <int S>
 __global__ void __launch_bounds__(512) rx_sym_rpack_kernel(const RxParams p) {
   using L = RPackLayout<S>;
   constexpr uint32_t SID_SHIFT = 24, SID_MASK = 63u << SID_SHIFT, ACC = RXE_ACCEPT, KEEP = RXE_TGT_MASK | RXE_ACCEPT;
+  const uint32_t keepf = p.reg_tmask | RXE_ACCEPT;  // fast word: value field (narrow automata keep look-ahead bits above it)
   constexpr uint32_t KEY = RXE_TGT_MASK | SID_MASK;
   static_assert(S >= 1 && S <= 64, "six-bit stream slot");
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -2037,7 +2047,7 @@ __global__ void __launch_bounds__(512) rx_sym_rpack_kernel(const RxParams p) {
       }
       if (__builtin_expect(macc != 0ull, 0)) pulses(k);
       const uint32_t xf = x.x, xs = x.y, e_in = e;
-      e = (xf & KEEP) | (e & SID_MASK);  // every lane's in-place update, precomputed (RXR_ACC sits on RXE_ACCEPT's bit)
+      e = (xf & keepf) | (e & SID_MASK);  // every lane's in-place update, precomputed (RXR_ACC sits on RXE_ACCEPT's bit)
       const uint64_t need = wballot((int)xf < 0), mp = wballot(vA != 0u);
       if (__builtin_expect((need | mp) != 0ull, 0)) {
         slow(k, xf, xs, vA, e_in);

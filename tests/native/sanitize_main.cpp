@@ -67,7 +67,23 @@ int main(int argc, char** argv) {
           CHECK(w == a.symidx_c[(size_t)s * ncls + k]);
           const bool inl = (w & RXE_INLINE) && !(fold && (w & RXE_PIN));
           const bool own = inl && !(w & RXE_SELF) && !(w & RXE_MAYDUP);
-          CHECK((f & RXE_TGT_MASK) == ((w & RXE_SELF) ? s : own ? (w & RXE_TGT_MASK) : a.size));
+          CHECK(a.reg_tmask == (a.size < 65536u ? 0xFFFFu : RXE_TGT_MASK));
+          CHECK((f & a.reg_tmask) == ((w & RXE_SELF) ? s : own ? (w & RXE_TGT_MASK) : a.size));
+          if (a.reg_tmask == 0xFFFFu) {
+            // look-ahead bits: nothing without a need, all ones for lists, else bit (n & 7) set iff the single target is an
+            // accept state or has an edge on a class n' with n' & 7 == n & 7
+            const uint32_t lv = (f >> 16) & 0xFFu;
+            if (!(f & RXR_NEED)) CHECK(lv == 0u);
+            else if (w & RXE_OVF) CHECK(lv == 0xFFu);
+            else {
+              const uint32_t t = w & RXE_TGT_MASK;
+              uint32_t want = 0;
+              for (uint32_t n = 0; n < ncls; n++)
+                if (a.symidx_c[(size_t)t * ncls + n] != 0u) want |= 1u << (n & 7u);
+              if (w & RXE_ACCEPT) want = 0xFFu;
+              CHECK(lv == want);
+            }
+          }
           CHECK(((f & RXR_NEED) != 0) == ((inl && !own) || (w & RXE_OVF)));
           CHECK(((f & RXR_ACC) != 0) == (own && (w & RXE_ACCEPT)));
           CHECK(((f & RXR_EXTRA) != 0) == (inl && !own && !(w & RXE_MAYDUP)) && ((f & RXR_DUPC) != 0) == (inl && (w & RXE_MAYDUP) != 0));
