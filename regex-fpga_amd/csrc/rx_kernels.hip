@@ -1700,7 +1700,25 @@ __global__ void __launch_bounds__(64) rx_sym_reg_kernel(const RxParams p) {
       macc = wballot(xf & RXR_ACC);                  // built while the gather is in flight
     } else {
       macc = wballot(xf & RXR_ACC);
-      slow(k, xs, (xf & nm) != 0u, e_in, vA);
+      // Most such passes have exactly ONE single target to place — the folded state's emission, or the target of one
+      // lane: straight-line code for that (the general path below is three loops and ~100 instructions).
+      uint32_t tw = 0u;
+      if (need == 0ull) tw = vA;
+      else if (vA == 0u && (need & (need - 1ull)) == 0ull) tw = bcast(xs, (uint32_t)__builtin_ctzll(need));
+      bool done = false;
+      if ((tw & RXE_INLINE) && !(FOLD && (tw & RXE_PIN))) {
+        const uint32_t t = tw & RXE_TGT_MASK;
+        const uint64_t mfree = wballot(e == FREE);
+        if ((tw & RXE_MAYDUP) && wballot(e == t) != 0ull) {
+          done = true;                                // already in the next set
+        } else if (mfree != 0ull) {
+          const uint32_t dst = (uint32_t)__builtin_ctzll(mfree);
+          if (lane == dst) e = t;
+          if (tw & RXE_ACCEPT) macc |= 1ull << dst;
+          done = true;
+        }
+      }
+      if (!done) slow(k, xs, (xf & nm) != 0u, e_in, vA);
       x = gather(cn);
     }
   };
