@@ -647,7 +647,7 @@ static int ensure_spill_area(rx_plan* p, RxParams& a) {
 // RX_KERNEL_AUTO: the fastest kernel depends on how many states are active per stream, which depends on
 // the input.  Probe: the pack kernel's statistics build over a corner of the batch (<= 512 streams x <= 1024
 // bytes, no outputs), then: small active sets -> pack kernel, larger ones -> wavefront-per-stream slice kernel.
-static int auto_probe(rx_plan* p) {
+static int auto_probe_pack(rx_plan* p) {
   p->auto_kernel = RX_KERNEL_SYM_PACK;
   p->auto_lanes = 16;
   p->auto_prune = false;
@@ -769,6 +769,68 @@ static int auto_probe(rx_plan* p) {
   return RX_OK;
 }
 
+// Small batches: with at most four wavefronts per SIMD the pack kernel is bound by the latency of its pass (a batch of 64
+// streams takes as long as one of 4 096), and one wavefront per stream on the register kernel is usually the shorter
+// chain (snort_16, 1 KB streams: 0.29 against 0.61 ms at 16 streams, 0.35 / 0.52 at 1 024, 0.45 / 0.53 at 4 096; l7:
+// 0.23 / 0.48) — unless the automaton places many targets per pass (the rule-set stand-in: 1.45 against 0.79 ms).  So AUTO
+// asks the hardware: both candidates run the probe's sample once more, timed.  Batches too small for a probe go to the
+// register kernel when the folded state's emissions are single targets (no folding table: when few cells hold lists).
+static int auto_probe(rx_plan* p, bool reg_eligible) {
+  int rc = auto_probe_pack(p);
+  if (rc || !reg_eligible) return rc;
+  const RxHostNfa& h = p->nfa->h;
+  if (p->n_streams * p->stream_len < (256u << 10)) {
+    size_t nz = 0, ov = 0;
+    if (!h.pin_tab.empty()) {
+      for (uint32_t w : h.pin_tab) { nz += w != 0u; ov += (w & RXE_OVF) != 0u; }
+    } else {
+      for (uint32_t w : h.symidx_c) { nz += w != 0u; ov += (w & RXE_OVF) != 0u; }
+    }
+    if (ov * 4u <= nz) p->auto_kernel = RX_KERNEL_SYM_REG;
+    return RX_OK;
+  }
+  if (p->auto_kernel != RX_KERNEL_SYM_PACK) return RX_OK;  // (many active states per stream: neither of the two)
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  auto timed = [&](uint32_t kernel, float* ms) -> int {
+    RxParams a;
+    fill_common(p, a);
+    a.n_streams = (uint32_t)std::min<size_t>(p->n_streams, 512);
+    a.stream_len = (uint32_t)std::min<size_t>(p->stream_len, 1024);
+    a.n_passes = a.stream_len + 1;
+    a.n_consume = a.stream_len;
+    RxLaunchCfg cfg{};
+    cfg.group_lanes = p->auto_lanes;
+    int r = rx_pick_launch(kernel, a.size, a.n_streams, p->tab.cu_count, p->tab.lds_per_cu, &a, &cfg);
+    if (r) return r;
+    cfg.prune = kernel == RX_KERNEL_SYM_PACK && p->auto_prune;
+    cfg.fold = kernel == RX_KERNEL_SYM_REG ? p->tab.pin_tab != nullptr : p->auto_fold;
+    if ((r = ensure_spill_area(p, a))) return r;
+    p->sets_clean = false;
+    for (int it = 0; it < 2; it++) {  // (the first launch of a kernel pays for its code object and attributes)
+      HIPCHK(hipMemsetAsync(p->d_counters, 0, 16 * sizeof(unsigned long long), p->stream));
+      HIPCHK(hipEventRecord(e0, p->stream));
+      hipError_t e = (hipError_t)rx_launch(a, cfg, p->stream);
+      if (e != hipSuccess) return hip_fail(e, "probe launch");
+      HIPCHK(hipEventRecord(e1, p->stream));
+    }
+    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipEventElapsedTime(ms, e0, e1));
+    return RX_OK;
+  };
+  float t_pack = 0.f, t_reg = 0.f;
+  rc = timed(RX_KERNEL_SYM_PACK, &t_pack);
+  if (!rc) rc = timed(RX_KERNEL_SYM_REG, &t_reg);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc) return rc;
+  if (p->opts.flags & RX_OPT_VERBOSE)
+    fprintf(stderr, "[rxmatch] probe: sample on the pack kernel %.3f ms, one wavefront per stream %.3f ms\n", t_pack, t_reg);
+  if (t_reg < 0.9f * t_pack) p->auto_kernel = RX_KERNEL_SYM_REG;
+  return RX_OK;
+}
+
 // Everything a launch decides before anything is enqueued for it: kernel arguments for the whole batch (p->params),
 // kernel choice (AUTO's probe runs here when its decision is not valid for the batch) and launch geometry (p->cfg).
 static int prepare_launch(rx_plan* p) {
@@ -800,13 +862,15 @@ static int prepare_launch(rx_plan* p) {
   a.pair_cycles = pair ? 1u : 0u;
   // few long streams from reset (the reference's own run is one lock-step pair): latency per pass is what counts, and the
   // register-resident kernel has the shortest pass; it has no statistics build
-  if (kernel == RX_KERNEL_AUTO && p->n_streams <= 4 && p->opts.collect_stats == 0 && !p->have_init && p->tab.regidx)
-    kernel = RX_KERNEL_SYM_REG;
+  const bool reg_ok = p->opts.collect_stats == 0 && !p->have_init && p->tab.regidx;
+  if (kernel == RX_KERNEL_AUTO && p->n_streams <= 4 && reg_ok) kernel = RX_KERNEL_SYM_REG;
+  // (more streams, but not enough to give every SIMD more than four wavefronts of them: the probe times both kernels)
+  const bool reg_eligible = kernel == RX_KERNEL_AUTO && reg_ok && p->n_streams <= 16u * (size_t)std::max(p->tab.cu_count, 1);
   // the probe also serves an explicit RX_KERNEL_SYM_PACK: whether look-ahead pruning pays depends on the input
   const bool probe_for_pack = kernel == RX_KERNEL_SYM_PACK && p->tab.symidx_p && p->opts.collect_stats == 0;
   if ((kernel == RX_KERNEL_AUTO || probe_for_pack) && !pair && !p->have_init) {
     if (!p->auto_decided) {
-      if ((rc = auto_probe(p))) return rc;
+      if ((rc = auto_probe(p, reg_eligible))) return rc;
       p->auto_decided = true;
       if (p->opts.flags & RX_OPT_VERBOSE)
         fprintf(stderr, "[rxmatch] AUTO -> kernel %u, %u streams per wavefront, look-ahead pruning %s, folding %s\n",

@@ -184,9 +184,10 @@ def test_compiled_ruleset_on_gpu(rx, orx):
 
 @pytest.mark.gpu
 def test_auto_probe_picks_the_kernel_by_active_set_size(rx, orx):
-    """RX_KERNEL_AUTO probes the batch: snort_16 trace windows (2-3 active states per stream) and the ruleset
-    stand-in (about 14, bursts of 70) both go to the pack kernel (16 resp. 4 streams per wavefront); an automaton
-    that keeps 300 states active goes to the wavefront-per-stream slice kernel — with identical results."""
+    """RX_KERNEL_AUTO probes the batch: the ruleset stand-in (about 14 active states per stream, bursts of 70, many targets
+    per pass) goes to the pack kernel; an automaton that keeps 300 states active goes to the wavefront-per-stream slice
+    kernel; snort_16 trace windows (2-3 active states) go to the pack kernel when the batch gives every SIMD more than four
+    wavefronts, and to one wavefront per stream on the register kernel when it is smaller — with identical results."""
     wl = rx.workloads
     from nfa_util import blowup_nfa
     W, size = blowup_nfa(300)
@@ -213,5 +214,11 @@ def test_auto_probe_picks_the_kernel_by_active_set_size(rx, orx):
         assert g2["stats"]["alg_bytes"] == ref["stats"]["alg_bytes"], kern
     snort = rx.Nfa.load_coe(wl.SNORT_COE)
     lo, hi = rx.load_mem(wl.TRACES[("snort_16", "lo")]), rx.load_mem(wl.TRACES[("snort_16", "hi")])
-    got = rx.match(snort, wl.trace_windows(lo, hi, 640, 1024))
-    assert rx.host.KERNEL_NAMES[got["stats"]["kernel_used"]] == "sym_pack"
+    rows = wl.trace_windows(lo, hi, 640, 1024)
+    got = rx.match(snort, rows)
+    assert rx.host.KERNEL_NAMES[got["stats"]["kernel_used"]] == "sym_reg"      # small batch: latency per pass is what counts
+    ref = orx.match_batch(snort.words, snort.size, rows)
+    assert got["n_events"] == ref["n_events"] and np.array_equal(got["final_active"], ref["final_active"])
+    big = rx.match(snort, wl.trace_windows(lo, hi, 8192, 1024))
+    assert rx.host.KERNEL_NAMES[big["stats"]["kernel_used"]] == "sym_pack"
+    assert np.array_equal(big["final_active"][:640], got["final_active"])
