@@ -790,9 +790,16 @@ static int auto_probe(rx_plan* p, bool reg_eligible) {
     return RX_OK;
   }
   if (p->auto_kernel != RX_KERNEL_SYM_PACK) return RX_OK;  // (many active states per stream: neither of the two)
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  HIPCHK(hipEventCreate(&e0));
-  HIPCHK(hipEventCreate(&e1));
+  struct EventPair {  // (destroyed on every path out of the probe)
+    hipEvent_t a = nullptr, b = nullptr;
+    ~EventPair() {
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+    }
+  } ev;
+  HIPCHK(hipEventCreate(&ev.a));
+  HIPCHK(hipEventCreate(&ev.b));
+  const hipEvent_t e0 = ev.a, e1 = ev.b;
   auto timed = [&](uint32_t kernel, float* ms) -> int {
     RxParams a;
     fill_common(p, a);
@@ -822,8 +829,6 @@ static int auto_probe(rx_plan* p, bool reg_eligible) {
   float t_pack = 0.f, t_reg = 0.f;
   rc = timed(RX_KERNEL_SYM_PACK, &t_pack);
   if (!rc) rc = timed(RX_KERNEL_SYM_REG, &t_reg);
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   if (rc) return rc;
   if (p->opts.flags & RX_OPT_VERBOSE)
     fprintf(stderr, "[rxmatch] probe: sample on the pack kernel %.3f ms, one wavefront per stream %.3f ms\n", t_pack, t_reg);

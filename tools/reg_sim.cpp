@@ -33,9 +33,9 @@ int main(int argc, char** argv) {
       std::set<uint32_t> vals;
       for (uint32_t k = 0; k < ncls; k++) {
         uint32_t f = h.regidx[((size_t)s * ncls + k) * 2];
-        if ((f & RXE_TGT_MASK) != FREE || (f & RXR_NEED)) nz++, vals.insert(f);
+        if ((f & h.reg_tmask) != FREE || (f & RXR_NEED)) nz++, vals.insert(f);
         if (f & RXR_NEED) need++;
-        if ((f & RXE_TGT_MASK) == s) self++;
+        if ((f & h.reg_tmask) == s) self++;
       }
       hist[nz > 8 ? 9 : nz]++;
       if (vals.size() <= 1 && need == 0) simple++;
@@ -62,7 +62,7 @@ int main(int argc, char** argv) {
     }
     printf("states a one-special-class descriptor cannot hold: %d of %u\n", nc, size);
   }
-  unsigned long long cl1 = 0, cl2 = 0, cpass = 0, slow_la = 0, slow_la1 = 0, kept = 0, kept1 = 0;
+  unsigned long long cl1 = 0, cl2 = 0, cpass = 0, slow_la = 0, slow_la1 = 0, slow_la8 = 0, kept = 0, kept1 = 0;
   std::vector<uint32_t> e(1, 0u);  // lanes in use (no FREE kept)
   unsigned long long slow = 0, c_extra = 0, c_dupc = 0, c_ovfl = 0, c_va_inl = 0, c_va_ovf = 0, places = 0, dupchecks = 0, act = 0, maxact = 0;
   unsigned long long p_extra = 0, p_dupc = 0, p_ovfl = 0, p_va = 0, only_va = 0, moved = 0, complexlanes = 0;
@@ -77,7 +77,7 @@ int main(int argc, char** argv) {
     for (uint32_t s : e) {
       const uint32_t f = h.regidx[((size_t)s * ncls + c) * 2], w = h.regidx[((size_t)s * ncls + c) * 2 + 1];
       hot[s]++;
-      const uint32_t v = f & RXE_TGT_MASK;
+      const uint32_t v = f & h.reg_tmask;
       if (v != FREE) { nx.push_back(v); if (v != s) moved++; }
       if (f & RXR_NEED) {
         if (f & RXR_EXTRA) ne++, cand_nodup.push_back(w);
@@ -86,7 +86,13 @@ int main(int argc, char** argv) {
       }
     }
     {  // with one byte of look-ahead on the single targets too (exact, and the one-live-class approximation)
-      int keep = 0, keep1 = 0;
+      int keep = 0, keep1 = 0, keep8 = 0;
+      auto live8 = [&](uint32_t w) {  // what the kernel does: the target's classes mod 8 (RxParams::reg_tmask)
+        const uint32_t t = w & RXE_TGT_MASK;
+        if ((w & RXE_ACCEPT) || k + 2 >= n) return true;
+        for (uint32_t q = cn & 7u; q < ncls; q += 8u) if (h.symidx_c[(size_t)t * ncls + q] != 0u) return true;
+        return false;
+      };
       auto live = [&](uint32_t w, bool one) {
         const uint32_t t = w & RXE_TGT_MASK;
         if (w & RXE_ACCEPT) return true;
@@ -94,8 +100,9 @@ int main(int argc, char** argv) {
         if (one) { int nl = 0; for (uint32_t q = 0; q < ncls; q++) nl += h.symidx_c[(size_t)t * ncls + q] != 0; if (nl != 1) return true; }
         return h.symidx_c[(size_t)t * ncls + cn] != 0u;
       };
-      for (uint32_t w : cand_nodup) keep += live(w, false), keep1 += live(w, true);
-      for (uint32_t w : cand_dup) keep += live(w, false), keep1 += live(w, true);
+      for (uint32_t w : cand_nodup) keep += live(w, false), keep1 += live(w, true), keep8 += live8(w);
+      for (uint32_t w : cand_dup) keep += live(w, false), keep1 += live(w, true), keep8 += live8(w);
+      if (keep8 || no || vA) slow_la8++;
       if (keep || no || vA) slow_la++;
       if (keep1 || no || vA) slow_la1++;
       kept += keep; kept1 += keep1;
@@ -127,7 +134,7 @@ int main(int argc, char** argv) {
          p_ovfl / P, p_va / P, only_va / P);
   printf("per pass: EXTRA lanes %.3f DUPC lanes %.3f OVFL lanes %.3f; emissions inline %.3f list %.3f; place() calls %.3f, of them with duplicate check %.3f\n",
          c_extra / P, c_dupc / P, c_ovfl / P, c_va_inl / P, c_va_ovf / P, places / P, dupchecks / P);
-  printf("with look-ahead on single targets: passes needing placement %.3f (exact), %.3f (targets with one live class only); single targets placed per pass %.3f / %.3f\n", slow_la / P, slow_la1 / P, kept / P, kept1 / P);
+  printf("with look-ahead on single targets: passes needing placement %.3f (exact), %.3f (classes mod 8, as built), %.3f (targets with one live class only); single targets placed per pass %.3f / %.3f\n", slow_la / P, slow_la8 / P, slow_la1 / P, kept / P, kept1 / P);
   printf("lane-passes on states without a descriptor: same-action multi-class %.4f, other %.4f per pass; passes with any %.4f\n", cl1 / P, cl2 / P, cpass / P);
   // which states hold lanes
   std::vector<std::pair<unsigned long long, uint32_t>> hv;
@@ -141,8 +148,8 @@ int main(int argc, char** argv) {
     int nz = 0, self = 0, need = 0;
     for (uint32_t k = 0; k < ncls; k++) {
       uint32_t f = h.regidx[((size_t)hv[i].second * ncls + k) * 2];
-      if ((f & RXE_TGT_MASK) != FREE || (f & RXR_NEED)) nz++;
-      if ((f & RXE_TGT_MASK) == hv[i].second) self++;
+      if ((f & h.reg_tmask) != FREE || (f & RXR_NEED)) nz++;
+      if ((f & h.reg_tmask) == hv[i].second) self++;
       if (f & RXR_NEED) need++;
     }
     printf("  state %5u  share %.3f cum %.3f  live classes %d self %d need %d\n", hv[i].second, (double)hv[i].first / tot, (double)cum / tot, nz, self, need);
