@@ -170,7 +170,8 @@ enum {
   RX_OPT_VERBOSE = 4u,      /* print AUTO's probe figures / choice and the launch geometry to stderr               */
   RX_OPT_PROFILE_PACK = 8u, /* SYM_PACK S=16: the s_memtime-stamped diagnostic build (phase shares on stderr)     */
   RX_OPT_NO_FOLD = 16u,     /* SYM_PACK: never fold the always-on `.*` state out of the lists                     */
-  RX_OPT_FORCE_FOLD = 32u   /* SYM_PACK: fold it whenever the automaton has such a state                          */
+  RX_OPT_FORCE_FOLD = 32u,  /* SYM_PACK: fold it whenever the automaton has such a state                          */
+  RX_OPT_REG_NO_SKIP = 64u  /* SYM_REG: the build that does not step over passes in which no state is active (A/B runs) */
 };
 
 /* One accept pulse: `state` was active and accepting in pass `k` of stream `stream`.

@@ -378,6 +378,7 @@ struct rx_plan {
   uint32_t auto_lanes = 16;    // streams per wavefront chosen for the pack kernel
   bool auto_prune = false;     // look-ahead pruning chosen (and verified at auto_lanes) by the probe
   bool auto_fold = false;      // always-on-state folding chosen (and verified at auto_lanes) by the probe
+  bool auto_reg_skip = true;   // register kernel: the build that steps over idle passes (AUTO's trial / timed choice)
   bool probe_prune = false;    // the probe's statistics say pruning pays (used when the caller fixes the kernel)
   double probe_active = 0;     // active states per stream-byte seen by the probe
   RxParams params{};
@@ -743,6 +744,11 @@ static int auto_probe_pack(rx_plan* p) {
     static const uint32_t fold_s[] = {16, 24, 32, 48, 64};
     uint32_t lanes = 16;
     for (uint32_t c : fold_s) if ((double)c <= per_simd / 2.0) lanes = c;
+    // Lists that are empty nearly all the time: the FOLD build skips the passes in which nothing happens to ANY of a
+    // wavefront's streams, so fewer streams per wavefront mean more passes skipped, and 16 streams are exactly one
+    // wave-load of the window refill (uniform bytes, ms: 65 536 streams S=16 0.206 / S=32 0.274 / S=64 0.426; 131 072:
+    // 0.387 / 0.537 / 0.477; 262 144: 0.714 / 0.849 / 0.924; 32 768: S=8 0.147, S=16 0.160)
+    if (left <= 0.03) lanes = per_simd >= 48.0 ? 16u : 8u;
     if (dbg) fprintf(stderr, "[rxmatch] probe: folded build leaves %.3f list entries per stream-byte, hand-offs %.1f %% -> %s\n", left,
                      100.0 * spilled, (left <= 0.3 && spilled <= 0.02) ? "fold" : "no fold");
     if (left <= 0.3 && spilled <= 0.02) { p->auto_lanes = lanes; p->auto_fold = true; p->auto_prune = prune; return RX_OK; }
@@ -769,12 +775,14 @@ static int auto_probe_pack(rx_plan* p) {
   return RX_OK;
 }
 
-// Small batches: with at most four wavefronts per SIMD the pack kernel is bound by the latency of its pass (a batch of 64
-// streams takes as long as one of 4 096), and one wavefront per stream on the register kernel is usually the shorter
-// chain (snort_16, 1 KB streams: 0.29 against 0.61 ms at 16 streams, 0.35 / 0.52 at 1 024, 0.45 / 0.53 at 4 096; l7:
-// 0.23 / 0.48) — unless the automaton places many targets per pass (the rule-set stand-in: 1.45 against 0.79 ms).  So AUTO
-// asks the hardware: both candidates run the probe's sample once more, timed.  Batches too small for a probe go to the
-// register kernel when the folded state's emissions are single targets (no folding table: when few cells hold lists).
+// Small batches: with few wavefronts per SIMD the pack kernel is bound by the latency of its pass (a batch of 64 streams
+// takes as long as one of 4 096), and one wavefront per stream on the register kernel is usually the shorter chain
+// (snort_16, 1 KB streams: 0.29 against 0.61 ms at 16 streams, 0.35 / 0.52 at 1 024, 0.45 / 0.53 at 4 096; uniform bytes,
+// where it skips the passes in which nothing is active: 0.02 / 0.42 at 16, 0.04 / 0.28 at 4 096; l7: 0.23 / 0.48) — unless
+// the automaton places many targets per pass (the rule-set stand-in: 1.45 against 0.79 ms).  So for batches of up to 16
+// wavefronts per SIMD AUTO asks the hardware: both candidates run the batch once, timed, without outputs.  Batches too
+// small for a probe go to the register kernel when the folded state's emissions are single targets (no folding table:
+// when few cells hold lists).
 static int auto_probe(rx_plan* p, bool reg_eligible) {
   int rc = auto_probe_pack(p);
   if (rc || !reg_eligible) return rc;
@@ -787,6 +795,7 @@ static int auto_probe(rx_plan* p, bool reg_eligible) {
       for (uint32_t w : h.symidx_c) { nz += w != 0u; ov += (w & RXE_OVF) != 0u; }
     }
     if (ov * 4u <= nz) p->auto_kernel = RX_KERNEL_SYM_REG;
+    p->auto_reg_skip = !h.pin_tab.empty();
     return RX_OK;
   }
   if (p->auto_kernel != RX_KERNEL_SYM_PACK) return RX_OK;  // (many active states per stream: neither of the two)
@@ -800,22 +809,26 @@ static int auto_probe(rx_plan* p, bool reg_eligible) {
   HIPCHK(hipEventCreate(&ev.a));
   HIPCHK(hipEventCreate(&ev.b));
   const hipEvent_t e0 = ev.a, e1 = ev.b;
-  auto timed = [&](uint32_t kernel, float* ms) -> int {
-    RxParams a;
-    fill_common(p, a);
-    a.n_streams = (uint32_t)std::min<size_t>(p->n_streams, 512);
-    a.stream_len = (uint32_t)std::min<size_t>(p->stream_len, 1024);
-    a.n_passes = a.stream_len + 1;
-    a.n_consume = a.stream_len;
-    RxLaunchCfg cfg{};
-    cfg.group_lanes = p->auto_lanes;
-    int r = rx_pick_launch(kernel, a.size, a.n_streams, p->tab.cu_count, p->tab.lds_per_cu, &a, &cfg);
-    if (r) return r;
-    cfg.prune = kernel == RX_KERNEL_SYM_PACK && p->auto_prune;
-    cfg.fold = kernel == RX_KERNEL_SYM_REG ? p->tab.pin_tab != nullptr : p->auto_fold;
-    if ((r = ensure_spill_area(p, a))) return r;
-    p->sets_clean = false;
-    for (int it = 0; it < 2; it++) {  // (the first launch of a kernel pays for its code object and attributes)
+  // one warm-up launch on the probe's corner of the batch (the first launch of a kernel pays for its code object), then
+  // the WHOLE batch, timed, without outputs: between 4 and 16 wavefronts per SIMD neither kernel's time can be read off
+  // a smaller sample (the register kernel grows with the batch, the pack kernel does not), and the batch is small
+  auto timed = [&](uint32_t kernel, bool reg_skip, float* ms) -> int {
+    for (int it = 0; it < 2; it++) {
+      RxParams a;
+      fill_common(p, a);
+      a.n_streams = it == 0 ? (uint32_t)std::min<size_t>(p->n_streams, 512) : (uint32_t)p->n_streams;
+      a.stream_len = it == 0 ? (uint32_t)std::min<size_t>(p->stream_len, 1024) : (uint32_t)p->stream_len;
+      a.n_passes = a.stream_len + 1;
+      a.n_consume = a.stream_len;
+      RxLaunchCfg cfg{};
+      cfg.group_lanes = p->auto_lanes;
+      int r = rx_pick_launch(kernel, a.size, a.n_streams, p->tab.cu_count, p->tab.lds_per_cu, &a, &cfg);
+      if (r) return r;
+      cfg.prune = kernel == RX_KERNEL_SYM_PACK && p->auto_prune;
+      cfg.fold = kernel == RX_KERNEL_SYM_REG ? p->tab.pin_tab != nullptr : p->auto_fold;
+      cfg.reg_skip = reg_skip;
+      if ((r = ensure_spill_area(p, a))) return r;
+      p->sets_clean = false;
       HIPCHK(hipMemsetAsync(p->d_counters, 0, 16 * sizeof(unsigned long long), p->stream));
       HIPCHK(hipEventRecord(e0, p->stream));
       hipError_t e = (hipError_t)rx_launch(a, cfg, p->stream);
@@ -826,13 +839,16 @@ static int auto_probe(rx_plan* p, bool reg_eligible) {
     HIPCHK(hipEventElapsedTime(ms, e0, e1));
     return RX_OK;
   };
-  float t_pack = 0.f, t_reg = 0.f;
-  rc = timed(RX_KERNEL_SYM_PACK, &t_pack);
-  if (!rc) rc = timed(RX_KERNEL_SYM_REG, &t_reg);
+  float t_pack = 0.f, t_reg = 0.f, t_skip = 0.f;
+  rc = timed(RX_KERNEL_SYM_PACK, false, &t_pack);
+  if (!rc) rc = timed(RX_KERNEL_SYM_REG, false, &t_reg);
+  if (!rc) rc = timed(RX_KERNEL_SYM_REG, true, &t_skip);
   if (rc) return rc;
   if (p->opts.flags & RX_OPT_VERBOSE)
-    fprintf(stderr, "[rxmatch] probe: sample on the pack kernel %.3f ms, one wavefront per stream %.3f ms\n", t_pack, t_reg);
-  if (t_reg < 0.9f * t_pack) p->auto_kernel = RX_KERNEL_SYM_REG;
+    fprintf(stderr, "[rxmatch] probe: the batch on the pack kernel %.3f ms, one wavefront per stream %.3f ms, stepping over idle "
+                    "passes %.3f ms\n", t_pack, t_reg, t_skip);
+  p->auto_reg_skip = t_skip < t_reg;
+  if (std::min(t_reg, t_skip) < 0.95f * t_pack) p->auto_kernel = RX_KERNEL_SYM_REG;
   return RX_OK;
 }
 
@@ -868,9 +884,41 @@ static int prepare_launch(rx_plan* p) {
   // few long streams from reset (the reference's own run is one lock-step pair): latency per pass is what counts, and the
   // register-resident kernel has the shortest pass; it has no statistics build
   const bool reg_ok = p->opts.collect_stats == 0 && !p->have_init && p->tab.regidx;
-  if (kernel == RX_KERNEL_AUTO && p->n_streams <= 4 && reg_ok) kernel = RX_KERNEL_SYM_REG;
-  // (more streams, but not enough to give every SIMD more than four wavefronts of them: the probe times both kernels)
-  const bool reg_eligible = kernel == RX_KERNEL_AUTO && reg_ok && p->n_streams <= 16u * (size_t)std::max(p->tab.cu_count, 1);
+  if (kernel == RX_KERNEL_AUTO && p->n_streams <= 4 && reg_ok) {
+    kernel = RX_KERNEL_SYM_REG;
+    if (!p->auto_decided) {
+      // Which build: a trial run over the first 8 192 bytes with the one that steps over idle passes, which counts the
+      // groups of passes it skipped in the second half (the busier shipped trace: none after pass 680 — the `.*` states
+      // inside its patterns never leave once entered; the quieter one: 63 %).
+      p->auto_reg_skip = true;
+      if (p->stream_len >= 16384) {
+        RxParams t;
+        fill_common(p, t);
+        t.n_streams = (uint32_t)p->n_streams;
+        t.stream_len = 8192u;
+        t.n_passes = t.n_consume = 8192u;
+        RxLaunchCfg cfg{};
+        if ((rc = rx_pick_launch(RX_KERNEL_SYM_REG, t.size, t.n_streams, p->tab.cu_count, p->tab.lds_per_cu, &t, &cfg))) return rc;
+        cfg.fold = p->tab.pin_tab != nullptr;
+        cfg.reg_skip = true;
+        if ((rc = ensure_spill_area(p, t))) return rc;
+        p->sets_clean = false;
+        unsigned long long cnt[16];
+        HIPCHK(hipMemsetAsync(p->d_counters, 0, sizeof(cnt), p->stream));
+        hipError_t e = (hipError_t)rx_launch(t, cfg, p->stream);
+        if (e != hipSuccess) return hip_fail(e, "trial launch");
+        HIPCHK(hipMemcpyAsync(cnt, p->d_counters, sizeof(cnt), hipMemcpyDeviceToHost, p->stream));
+        HIPCHK(hipStreamSynchronize(p->stream));
+        p->auto_reg_skip = cnt[10] * 10u >= (unsigned long long)t.n_streams * 1024u;  // >= 10 % of the 1 024 groups per stream
+        if (p->opts.flags & RX_OPT_VERBOSE)
+          fprintf(stderr, "[rxmatch] register kernel trial: %llu of %u groups of passes idle -> %s\n", cnt[10], t.n_streams * 1024u,
+                  p->auto_reg_skip ? "step over them" : "plain build");
+      }
+      p->auto_decided = true;
+    }
+  }
+  // (more streams, but at most 16 wavefronts of them per SIMD: the probe times both kernels on the batch)
+  const bool reg_eligible = kernel == RX_KERNEL_AUTO && reg_ok && p->n_streams <= 64u * (size_t)std::max(p->tab.cu_count, 1);
   // the probe also serves an explicit RX_KERNEL_SYM_PACK: whether look-ahead pruning pays depends on the input
   const bool probe_for_pack = kernel == RX_KERNEL_SYM_PACK && p->tab.symidx_p && p->opts.collect_stats == 0;
   if ((kernel == RX_KERNEL_AUTO || probe_for_pack) && !pair && !p->have_init) {
@@ -922,6 +970,7 @@ static int prepare_launch(rx_plan* p) {
   }
   p->cfg.verbose = (p->opts.flags & RX_OPT_VERBOSE) != 0;
   p->cfg.profile_pack = (p->opts.flags & RX_OPT_PROFILE_PACK) != 0;
+  p->cfg.reg_skip = !(p->opts.flags & RX_OPT_REG_NO_SKIP) && (p->opts.kernel == RX_KERNEL_AUTO ? p->auto_reg_skip : true);
   // look-ahead pruning of multi-target rows follows the probe: AUTO's verified choice, or for an explicit
   // RX_KERNEL_SYM_PACK what the probe's statistics say.  rx_opts.flags RX_OPT_NO_PRUNE / RX_OPT_FORCE_PRUNE override it
   // (A/B measurements; tests, whose batches are too small for a probe).

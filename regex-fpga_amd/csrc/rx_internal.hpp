@@ -145,6 +145,7 @@ struct RxLaunchCfg {
   bool prune;              // SYM_PACK: look-ahead pruning of multi-target rows (needs RxParams::ovf_dir)
   bool fold;               // SYM_PACK: the pinned `.*` state is folded out of the lists (needs RxParams::pin_tab)
   bool verbose;            // rx_opts.flags & RX_OPT_VERBOSE: print the launch geometry
+  bool reg_skip;           // SYM_REG: the build that steps over groups of passes in which nothing is active
   bool profile_pack;       // rx_opts.flags & RX_OPT_PROFILE_PACK: stamped diagnostic build of the pack kernel (S=16)
 };
 

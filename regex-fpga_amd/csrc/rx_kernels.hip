@@ -798,7 +798,8 @@ struct PackLayout {
   static constexpr uint32_t WINW = (PRUNE || FOLD) ? 18 : 16;
   static constexpr uint32_t STRIDE = 2u * FW + WINW + 1u;   // + any-match word; odd => banks spread
   static constexpr uint32_t LISTW = CAPW + 128u;            // a sweep appends at most 128 entries past CAPW: no bounds check
-  static constexpr uint32_t WAVE_WORDS = 2u * LISTW + S * STRIDE + S;  // lists, stream regions, spill slots
+  // lists, stream regions, spill slots; FOLD: + which of the window's 64 passes have an emission of the folded state
+  static constexpr uint32_t WAVE_WORDS = 2u * LISTW + S * STRIDE + S + (FOLD ? 2u : 0u);
   static constexpr uint32_t CMAPW = 64;                     // byte -> class map (256 bytes), shared by the block
   // FOLD: the block also keeps the pinned state's folding table (RxParams::pin_tab) behind the class map
 };
@@ -841,6 +842,7 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
   uint32_t* wl = lds + L::CMAPW + pin_words + (size_t)wib * L::WAVE_WORDS;  // [2][CAPW] wave-wide lists
   uint32_t* sreg0 = wl + 2u * L::LISTW;              // [S][STRIDE]: filters[2][FW], window[WINW], am word
   uint32_t* slotw = sreg0 + S * L::STRIDE;           // [S] spill slots
+  uint32_t* busyw = slotw + S;                       // FOLD: [2] = 64 bits, one per pass of the current window
   const uint32_t* __restrict__ rp = p.words;
   constexpr bool prune = PRUNE;
   const uint32_t* __restrict__ symidx = PRUNE ? p.symidx_p : p.symidx_c;
@@ -906,6 +908,7 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
   const uint32_t x_none = (lane / (uint32_t)S) << 5;
   const uint32_t e_none = 0x80000000u | ((lane % (uint32_t)S) << SID_SHIFT) | x_none;
 
+  unsigned long long busy = ~0ull;  // FOLD: bit j = pass j of the current window has an emission of the folded state (wave-uniform)
   // window refill at a pass k that is a multiple of 64: bytes -> byte classes on the way into LDS, next window requested
   auto refill = [&](uint32_t k) {
     wave_sync();
@@ -922,8 +925,38 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
         }
       }
     }
+    if (FOLD) {
+      // Which passes of this window can be skipped when the wave's list is empty: those in which no stream's folded state
+      // emits anything (on inputs that rarely touch a pattern nearly all of them).  The lane that converted 16 bytes of
+      // a stream looks the 16 emissions up; pass 63 needs the next window's first byte and is added at mid-window
+      // (stash_next_first).
+      if (lane < 2u) busyw[lane] = 0u;
+      wave_sync();
+#pragma unroll
+      for (uint32_t g = 0; g < NLOAD; g++) {
+        const uint32_t slot = g * 16u + (lane >> 2), part = lane & 3u;
+        const uint32_t* win = sreg0 + (slot < n_mine ? slot : 0u) * L::STRIDE + 2u * L::FW + part * 4u;
+        const uint32_t w0 = win[0], w1 = win[1], w2 = win[2], w3 = win[3];
+        const uint32_t nf = (uint32_t)__shfl_down((int)(w0 & 0xFFu), 1);  // first class of the next 16 bytes (part < 3)
+        const unsigned long long lo = ((unsigned long long)w1 << 32) | w0, hi = ((unsigned long long)w3 << 32) | w2;
+        uint32_t bits = 0u;
+#pragma unroll
+        for (uint32_t i = 0; i < 16u; i++) {
+          const uint32_t c0 = (uint32_t)((i < 8u ? lo : hi) >> (8u * (i & 7u))) & 0xFFu;
+          const uint32_t c1 = i == 15u ? nf : (uint32_t)((i + 1u < 8u ? lo : hi) >> (8u * ((i + 1u) & 7u))) & 0xFFu;
+          const uint32_t kg = k + part * 16u + i;
+          const bool last = kg + 1u >= p.n_consume;
+          const bool known = kg >= 1u && kg < p.n_consume && (last || !(part == 3u && i == 15u));
+          const uint32_t em = known ? pintab[c0 * p.pin_cols + (last ? ncls : c1)] : 0u;
+          bits |= (em != 0u ? 1u : 0u) << i;
+        }
+        if (slot < n_mine && bits != 0u) atomicOr(&busyw[part >> 1], bits << ((part & 1u) * 16u));
+      }
+    }
     load_win((k >> 6) + 1u, nxt);
     wave_sync();
+    if (FOLD) busy = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)busyw[1]) << 32) |
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)busyw[0]);
   };
   // per-pass any-match bits of 32 passes: one word per stream, stored by the stream's owner lane
   auto store_anymatch = [&](uint32_t word) {
@@ -943,6 +976,15 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
     for (uint32_t g = 0; g < NLOAD; g++) {
       const uint32_t slot = g * 16u + (lane >> 2);
       if ((lane & 3u) == 0u && slot < n_mine) sreg0[slot * L::STRIDE + 2u * L::FW + 16u] = cmap[nxt[g][0] & 0xFFu];
+    }
+    if (FOLD) {  // pass 63 of the window: its look-ahead class has just arrived
+      wave_sync();
+      uint32_t em = 0u;
+      if (owner) {
+        const uint8_t* wb = reinterpret_cast<const uint8_t*>(sreg0 + lane * L::STRIDE + 2u * L::FW);
+        em = pintab[(uint32_t)wb[63] * p.pin_cols + (uint32_t)wb[64]];
+      }
+      if (wballot(em != 0u) != 0ull) busy |= 1ull << 63;
     }
   };
 
@@ -1231,6 +1273,16 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
     while (k < kend && !spilled) {
       const uint32_t k32 = kend - k < 32u ? kend : k + 32u;
       do {
+        if (FOLD && __builtin_amdgcn_readfirstlane((int)N) == 0) {
+          // nothing in the wave's list: the passes up to the next emission of a folded state change nothing at all
+          // (both lists empty, both filters clean, no pulse) — skip them in one step
+          const unsigned long long rest = busy >> (k & 63u);
+          if ((rest & 1ull) == 0ull) {
+            const uint32_t skip = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
+            k += skip < k32 - k ? skip : k32 - k;
+            continue;
+          }
+        }
         pass(k, std::true_type{});
         k++;
       } while (k < k32 && !spilled);
@@ -1574,7 +1626,11 @@ __global__ void __launch_bounds__(256) rx_dfa_kernel(const RxParams p) {
 //     multi-target rows, the folded state's targets — is flagged in the fast word and goes through a short scalar loop
 //     (v_readlane, first free lane, v_writelane): about every second pass on the busier shipped trace.
 // More than 64 active states: the stream is handed to the wave kernel (resume mode) like in the group / pack kernels.
-template <bool FOLD>
+// SKIP: groups of four passes in which no lane holds a state and the folded state emits nothing are stepped over (the
+// quieter shipped trace: 63 % of all passes; uniform bytes: nearly all).  A build of its own because the test, three
+// instructions per group, costs the other build's code 4-14 % through register allocation (measured: hi trace 42.4 ->
+// 44.7 ms, l7 small batches 0.23 -> 0.26 ms): AUTO picks per batch (rx_api.cpp).
+template <bool FOLD, bool SKIP>
 __global__ void __launch_bounds__(64) rx_sym_reg_kernel(const RxParams p) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const uint32_t lane = threadIdx.x & 63u;
@@ -1607,6 +1663,7 @@ __global__ void __launch_bounds__(64) rx_sym_reg_kernel(const RxParams p) {
   uint64_t macc = (p.state0_entry & RXE_ACCEPT) ? 1ull : 0ull;  // lanes that hold an accept state
   uint32_t am_word = 0;
   bool handed_off = false;
+  uint32_t n_skipped = 0;  // SKIP: groups stepped over in the second half of the stream (what AUTO's trial run reads)
   // shader clock the stream ran at (diagnostic; read by RX_OPT_VERBOSE): cycles and 100 MHz ticks of stream 0
   const unsigned long long t0c = __builtin_amdgcn_s_memtime(), t0r = __builtin_amdgcn_s_memrealtime();
 
@@ -1742,9 +1799,28 @@ __global__ void __launch_bounds__(64) rx_sym_reg_kernel(const RxParams p) {
       }
     }
     const uint32_t kchunk = n_consume - k < 256u ? n_consume : k + 256u;
+    // SKIP: groups of four passes of this chunk in which the folded state emits something (lane = group index; kept per
+    // lane and balloted only when needed: the loop below has no scalar register to spare)
+    const uint32_t gbusy_v = (SKIP && FOLD) ? (va[0] | va[1] | va[2] | va[3]) : 0u;
     // four passes on the classes of one SGPR pair, no per-pass loop tests; never the stream's last pass
     while (k + 4u <= kchunk && k + 4u < n_consume && !handed_off) {
       const uint32_t gi = (k >> 2) & 63u;
+      if (SKIP && __builtin_expect(macc == 0ull && wballot(e != FREE) == 0ull, 0)) {
+        // No active state but the folded one: until that state emits something again nothing happens at all — skip those
+        // groups of passes in one step (x holds the empty row's words, which are the same for every byte).
+        const unsigned long long rest = wballot(gbusy_v != 0u && lane >= gi) >> gi;  // bit 0 = this group
+        if ((rest & 1ull) == 0ull) {
+          uint32_t skip = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;   // groups
+          const uint32_t to_word = 8u - ((k >> 2) & 7u), to_chunk = (kchunk - k) >> 2, to_end = (n_consume - k - 1u) >> 2;
+          skip = skip < to_word ? skip : to_word;
+          skip = skip < to_chunk ? skip : to_chunk;
+          skip = skip < to_end ? skip : to_end;
+          if (k >= (n_consume >> 1)) n_skipped += skip;
+          k += 4u * skip;
+          if (p.anymatch && (k & 31u) == 0u) store_anymatch(k - 1u);
+          continue;
+        }
+      }
       const uint32_t c4 = bcast(cw, gi);
       const uint32_t c4n = gi == 63u ? bcast(cwn, 0) : bcast(cw, gi + 1u);
       pass(k, (c4 >> 8) & 0xFFu, FOLD ? bcast(va[0], gi) : 0u, true);
@@ -1783,6 +1859,7 @@ __global__ void __launch_bounds__(64) rx_sym_reg_kernel(const RxParams p) {
     p.counters[8] = __builtin_amdgcn_s_memtime() - t0c;
     p.counters[9] = __builtin_amdgcn_s_memrealtime() - t0r;
   }
+  if (SKIP && lane == 0 && n_skipped) atomicAdd(&p.counters[10], (unsigned long long)n_skipped);
   // final active set: the row was zeroed at the start of this kernel
   if (p.final_active && !handed_off) {
     uint32_t* row = p.final_active + (size_t)stream * p.nw64x2;
@@ -2254,8 +2331,12 @@ int rx_launch(const RxParams& p, const RxLaunchCfg& cfg, void* hip_stream) {
       } else if (cfg.kernel == RX_KERNEL_SYM_REG) {  // one wavefront (= one block) per stream
         const bool fold = cfg.fold && p.pin_tab;
         const uint32_t lds = 64u * 4u;  // the byte -> class map; the folding table is read with scalar loads
-        e = fold ? launch_one(rx_sym_reg_kernel<true>, p, p.n_streams, 64u, lds, s)
-                 : launch_one(rx_sym_reg_kernel<false>, p, p.n_streams, 64u, lds, s);
+        if (cfg.reg_skip)
+          e = fold ? launch_one(rx_sym_reg_kernel<true, true>, p, p.n_streams, 64u, lds, s)
+                   : launch_one(rx_sym_reg_kernel<false, true>, p, p.n_streams, 64u, lds, s);
+        else
+          e = fold ? launch_one(rx_sym_reg_kernel<true, false>, p, p.n_streams, 64u, lds, s)
+                   : launch_one(rx_sym_reg_kernel<false, false>, p, p.n_streams, 64u, lds, s);
       } else if (cfg.kernel == RX_KERNEL_DFA) {
         const uint32_t wpb = 4;
         const uint32_t grid = (p.n_streams + wpb * 64u - 1) / (wpb * 64u);

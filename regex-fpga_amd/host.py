@@ -17,7 +17,7 @@ KERNEL_AUTO, KERNEL_CSR_WAVE, KERNEL_SYM_WAVE, KERNEL_SYM_GROUP, KERNEL_SYM_PACK
 KERNEL_NAMES = {0: "auto", 1: "csr_wave", 2: "sym_wave", 3: "sym_group", 4: "sym_pack", 5: "dfa", 6: "sym_reg", 7: "sym_rpack"}
 
 # rx_opts.flags (A/B and diagnostic switches; read at plan creation, never from the environment)
-OPT_NO_PRUNE, OPT_FORCE_PRUNE, OPT_VERBOSE, OPT_PROFILE_PACK, OPT_NO_FOLD, OPT_FORCE_FOLD = 1, 2, 4, 8, 16, 32
+OPT_NO_PRUNE, OPT_FORCE_PRUNE, OPT_VERBOSE, OPT_PROFILE_PACK, OPT_NO_FOLD, OPT_FORCE_FOLD, OPT_REG_NO_SKIP = 1, 2, 4, 8, 16, 32, 64
 
 EVENT_DT = np.dtype([("stream", "<u4"), ("k", "<u4"), ("state", "<u4")])
 

@@ -32,8 +32,9 @@ def kernels(rx):
             dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=32, flags=rx.host.OPT_FORCE_FOLD),
             dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=48, flags=rx.host.OPT_FORCE_FOLD | rx.host.OPT_FORCE_PRUNE),
             dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=64, flags=rx.host.OPT_FORCE_FOLD),
-            # register-resident one-wavefront-per-stream kernel, folded (default) and unfolded
+            # register-resident one-wavefront-per-stream kernel, folded (default) and unfolded, with and without stepping over idle passes
             dict(kernel=rx.KERNEL_SYM_REG), dict(kernel=rx.KERNEL_SYM_REG, flags=rx.host.OPT_NO_FOLD),
+            dict(kernel=rx.KERNEL_SYM_REG, flags=rx.host.OPT_REG_NO_SKIP), dict(kernel=rx.KERNEL_SYM_REG, flags=rx.host.OPT_REG_NO_SKIP | rx.host.OPT_NO_FOLD),
             # many-streams register kernel (pack kernel on automata without a foldable state)
             dict(kernel=rx.KERNEL_SYM_RPACK, group_lanes=8), dict(kernel=rx.KERNEL_SYM_RPACK, group_lanes=16),
             dict(kernel=rx.KERNEL_SYM_RPACK, group_lanes=24), dict(kernel=rx.KERNEL_SYM_RPACK, group_lanes=32)]

@@ -79,7 +79,8 @@ def one_case(rng, trial):
     for kern in ks:
         stats = bool(rng.integers(2))  # the statistics build and the plain build are different kernels (pruning, marks)
         # batches here are too small for the probe that normally decides: force the pruned / folded builds half the time
-        flags = (rx.host.OPT_FORCE_PRUNE if rng.integers(2) else 0) | (rx.host.OPT_FORCE_FOLD if rng.integers(2) else 0)
+        flags = (rx.host.OPT_FORCE_PRUNE if rng.integers(2) else 0) | (rx.host.OPT_FORCE_FOLD if rng.integers(2) else 0) | \
+            (rx.host.OPT_REG_NO_SKIP if rng.integers(2) else 0)
         got = rx.match(nfa, rows, mode=mode, want_match_count=True, collect_stats=stats, events_cap=CAP, flags=flags, **kern)
         ok = (got["n_events"] == ref["n_events"] and (overflow or np.array_equal(got["events"], ref["events"].astype(got["events"].dtype)))
               and np.array_equal(got["match_count"], ref["match_count"]) and np.array_equal(got["final_active"], ref["final_active"])
