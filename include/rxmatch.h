@@ -136,15 +136,10 @@ enum {
   RX_KERNEL_SYM_REG = 6   /* one wavefront per stream, the active set register-resident (one state per lane, updated
                              in place: no LDS list, no filter), the always-on `.*` state folded out when the automaton
                              has one: the kernel for FEW LONG streams — the reference's own run is one lock-step pair
-                             (testbench_BLK_Mem.sv:49-87).  RX_KERNEL_AUTO picks it for up to 4 streams from reset;
+                             (testbench_BLK_Mem.sv:49-87).  RX_KERNEL_AUTO picks it for up to 4 streams from reset, and for batches of up to 16
+                             wavefronts per SIMD when a timed trial says so;
                              more than 64 active states: hand-off to RX_KERNEL_SYM_WAVE.  With collect_stats or a
                              caller-supplied start set RX_KERNEL_SYM_WAVE runs instead.                      */
-  ,
-  RX_KERNEL_SYM_RPACK = 7 /* the register kernel's recipe for MANY streams: S streams per wavefront (rx_opts.group_lanes =
-                             8/16/24/32, default 16) share the 64 lanes as entry slots, in-place precomputed updates, the
-                             `.*` state folded out, one vectorised placement per pass for what needs a lane of its own.
-                             Needs an automaton whose state 0 enters a `.*` state on every byte (else, and with
-                             collect_stats or a start set, RX_KERNEL_SYM_PACK / RX_KERNEL_SYM_WAVE run instead).  */
 };
 
 typedef struct rx_opts {

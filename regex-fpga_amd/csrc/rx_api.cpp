@@ -936,10 +936,8 @@ static int prepare_launch(rx_plan* p) {
   }
   // a caller-supplied start set is a bitmask row: that is the wave kernel's dense form
   if (p->have_init && (kernel == RX_KERNEL_AUTO || kernel == RX_KERNEL_SYM_GROUP || kernel == RX_KERNEL_SYM_PACK ||
-                       kernel == RX_KERNEL_DFA || kernel == RX_KERNEL_SYM_REG || kernel == RX_KERNEL_SYM_RPACK))
+                       kernel == RX_KERNEL_DFA || kernel == RX_KERNEL_SYM_REG))
     kernel = RX_KERNEL_SYM_WAVE;
-  // the many-streams register kernel has no statistics build and needs the folding table + the register index
-  if (kernel == RX_KERNEL_SYM_RPACK && (p->opts.collect_stats != 0 || !p->tab.regidx || !p->tab.pin_tab)) kernel = RX_KERNEL_SYM_PACK;
   if (kernel == RX_KERNEL_SYM_REG && (p->opts.collect_stats != 0 || !p->tab.regidx)) kernel = RX_KERNEL_SYM_WAVE;
   p->cfg.group_lanes = auto_lanes ? auto_lanes : p->opts.group_lanes;
   rc = rx_pick_launch(kernel, h.size, a.n_streams, p->tab.cu_count, p->tab.lds_per_cu, &a, &p->cfg);
@@ -951,15 +949,8 @@ static int prepare_launch(rx_plan* p) {
                 ((p->cfg.kernel == RX_KERNEL_SYM_PACK &&
                   ((p->opts.flags & RX_OPT_FORCE_FOLD) != 0 || (p->opts.kernel == RX_KERNEL_AUTO && p->auto_fold))) ||
                  p->cfg.kernel == RX_KERNEL_SYM_REG);  // the register kernel folds whenever the automaton allows
-  if (p->cfg.kernel == RX_KERNEL_SYM_REG || p->cfg.kernel == RX_KERNEL_SYM_RPACK)
+  if (p->cfg.kernel == RX_KERNEL_SYM_REG)
     p->cfg.fold = p->tab.pin_tab != nullptr;  // (their index is built for exactly that)
-  if (p->cfg.kernel == RX_KERNEL_SYM_RPACK) {
-    static const uint32_t rp_s[] = {8, 16, 24, 32};
-    uint32_t pick = 32;
-    const uint32_t want = p->opts.group_lanes ? p->opts.group_lanes : 16u;
-    for (uint32_t c : rp_s) if (want <= c) { pick = c; break; }
-    p->cfg.group_lanes = pick;
-  }
   if (p->cfg.fold && p->cfg.kernel == RX_KERNEL_SYM_PACK) {
     static const uint32_t fold_s[] = {8, 13, 16, 24, 32, 48, 64};
     uint32_t pick = 64;
@@ -978,7 +969,7 @@ static int prepare_launch(rx_plan* p) {
                  ((p->opts.flags & RX_OPT_FORCE_PRUNE) != 0 ||
                   (p->opts.kernel == RX_KERNEL_SYM_PACK ? p->probe_prune : p->opts.kernel == RX_KERNEL_AUTO && p->auto_prune));
   const bool two_tier = p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK ||
-                        p->cfg.kernel == RX_KERNEL_DFA || p->cfg.kernel == RX_KERNEL_SYM_REG || p->cfg.kernel == RX_KERNEL_SYM_RPACK;
+                        p->cfg.kernel == RX_KERNEL_DFA || p->cfg.kernel == RX_KERNEL_SYM_REG;
   if (two_tier && (rc = ensure_spill_area(p, a))) return rc;
   if (p->cfg.kernel == RX_KERNEL_DFA) {
     if (pair) return RX_EINVAL;
@@ -1160,12 +1151,12 @@ static int plan_download(rx_plan* p, rx_result* res) {
   st.n_events = cnt[0];
   st.kernel_ms = p->last_ms;
   st.kernel_used = p->cfg.kernel;
-  st.lanes_used = (p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK || p->cfg.kernel == RX_KERNEL_SYM_RPACK) ? p->cfg.group_lanes : 0u;
+  st.lanes_used = (p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK) ? p->cfg.group_lanes : 0u;
   st.variant = (p->cfg.stats ? RX_VARIANT_STATS : 0u) |
                (p->cfg.kernel == RX_KERNEL_SYM_PACK && p->cfg.prune && !p->cfg.stats && p->tab.symidx_p ? RX_VARIANT_PRUNE : 0u) |
                (p->cfg.fold ? RX_VARIANT_FOLD : 0u);
   st.n_launches = (p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK ||
-                   p->cfg.kernel == RX_KERNEL_DFA || p->cfg.kernel == RX_KERNEL_SYM_REG || p->cfg.kernel == RX_KERNEL_SYM_RPACK) ? 2 : 1;
+                   p->cfg.kernel == RX_KERNEL_DFA || p->cfg.kernel == RX_KERNEL_SYM_REG) ? 2 : 1;
   if (p->cfg.stats) {
     st.sum_active = cnt[1];
     st.sum_edges = cnt[2];
@@ -1311,7 +1302,7 @@ static int plan_run(rx_plan* p, const uint8_t* bytes, size_t n_streams, size_t s
   const size_t am_need = (size_t)((p->params.n_passes + 31) / 32);
   if (res->anymatch && res->anymatch_stride < am_need) return RX_EINVAL;
   const bool two_tier = p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK ||
-                        p->cfg.kernel == RX_KERNEL_DFA || p->cfg.kernel == RX_KERNEL_SYM_REG || p->cfg.kernel == RX_KERNEL_SYM_RPACK;
+                        p->cfg.kernel == RX_KERNEL_DFA || p->cfg.kernel == RX_KERNEL_SYM_REG;
   for (size_t b = 1; b < n_blocks; b++)  // all uploads are queued before any download (both use the same link)
     if ((rc = upload(b))) return rc;
   for (size_t b = 0; b < n_blocks; b++) {
@@ -1378,7 +1369,7 @@ static int plan_run(rx_plan* p, const uint8_t* bytes, size_t n_streams, size_t s
   st = rx_stats{};
   st.n_passes = p->params.n_passes;
   st.kernel_used = p->cfg.kernel;
-  st.lanes_used = (p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK || p->cfg.kernel == RX_KERNEL_SYM_RPACK) ? p->cfg.group_lanes : 0u;
+  st.lanes_used = (p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK) ? p->cfg.group_lanes : 0u;
   st.variant = (p->cfg.stats ? RX_VARIANT_STATS : 0u) |
                (p->cfg.kernel == RX_KERNEL_SYM_PACK && p->cfg.prune && !p->cfg.stats && p->tab.symidx_p ? RX_VARIANT_PRUNE : 0u) |
                (p->cfg.fold ? RX_VARIANT_FOLD : 0u);

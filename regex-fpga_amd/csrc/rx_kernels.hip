@@ -1868,314 +1868,6 @@ __global__ void __launch_bounds__(64) rx_sym_reg_kernel(const RxParams p) {
   }
 }
 
-// =================================================================================================
-// Kernel 7: register-resident active sets, S streams per wavefront
-// =================================================================================================
-// The pack kernel's pass costs a wavefront ~115 instructions whatever its lists hold, and instruction count per
-// stream-byte is what bounds it.  This kernel carries the register kernel's recipe over to many streams:
-//   * the 64 lanes are a pool of entry slots shared by the wave's S streams: a lane holds (state | stream slot << 24 |
-//     accept flag) or FREE; the in-place update is the precomputed fast word of RxParams::regidx (one v_bfi), every
-//     lane gathers unconditionally (FREE and accept states read an empty row);
-//   * a lane also carries the byte classes of ITS stream for the current and the next group of four passes (two VGPRs,
-//     refreshed from the stream's LDS window once per four passes), so the gather offset is two VALU instructions;
-//   * the always-on `.*` state is folded out (the stream's owner lane looks its emission up, as in the FOLD builds);
-//   * no lists, no filters, no atomics in the common pass.  What needs a lane of its own goes through ONE vectorised
-//     placement per pass — candidates write (entry, class words) to an LDS scratch at their rank, free lanes read the
-//     record at theirs — except targets that may already be in the set (RXE_MAYDUP: compared against all lanes, one at
-//     a time) and multi-target rows (scalar loops).
-// Needs the folding table and the register index (automata whose state 0 enters a `.*` state on every byte).  More
-// entries than lanes: the wave's streams are handed to the wave kernel like in the pack kernel.
-template <int S>
-struct RPackLayout {
-  static constexpr uint32_t WINW = 18;  // 64 byte classes + the look-ahead byte + pad (odd stride)
-  static constexpr uint32_t WSTR = WINW + 1u;
-  static constexpr uint32_t WAVE_WORDS = S * WSTR + 2u * S + 3u * 64u;  // windows, any-match words, spill slots, scratch
-};
-
-template <int S>
-__global__ void __launch_bounds__(512) rx_sym_rpack_kernel(const RxParams p) {
-  using L = RPackLayout<S>;
-  constexpr uint32_t SID_SHIFT = 24, SID_MASK = 63u << SID_SHIFT, ACC = RXE_ACCEPT, KEEP = RXE_TGT_MASK | RXE_ACCEPT;
-  const uint32_t keepf = p.reg_tmask | RXE_ACCEPT;  // fast word: value field (narrow automata keep look-ahead bits above it)
-  constexpr uint32_t KEY = RXE_TGT_MASK | SID_MASK;
-  static_assert(S >= 1 && S <= 64, "six-bit stream slot");
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wib = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-  uint32_t* cmapw = lds;
-  const uint8_t* cmap = reinterpret_cast<const uint8_t*>(cmapw);
-  const uint32_t pin_words = p.n_classes * p.pin_cols;
-  const uint32_t* pintab = lds + 64u;
-  uint32_t* win0 = lds + 64u + pin_words + (size_t)wib * L::WAVE_WORDS;  // [S][WSTR] class windows
-  uint32_t* amw = win0 + S * L::WSTR;                                    // [S] any-match bits of 32 passes
-  uint32_t* slotw = amw + S;                                             // [S] spill slots
-  uint32_t* scr_v = slotw + S;                                           // [64] placement scratch: entries,
-  uint32_t* scr_c = scr_v + 64u;                                         //      class words of the current group,
-  uint32_t* scr_n = scr_c + 64u;                                         //      class words of the next group
-  const uint32_t ncls = p.n_classes, ncls8 = ncls * 8u;
-  const uint32_t FREE = p.size;
-  const char* __restrict__ regidx = reinterpret_cast<const char*>(p.regidx);
-  const uint32_t* __restrict__ ovf = p.ovf;
-
-  zero_next_counters(p);
-  for (uint32_t w = threadIdx.x; w < 64u; w += blockDim.x) cmapw[w] = p.byte_class[w];
-  for (uint32_t w = threadIdx.x; w < pin_words; w += blockDim.x) lds[64u + w] = p.pin_tab[w];
-  __syncthreads();  // the only block-wide barrier; the waves never meet again
-
-  const uint32_t wave = blockIdx.x * wpb + wib;
-  const uint32_t stream0 = wave * S;
-  if (stream0 >= p.n_streams) return;
-  const uint32_t n_mine = p.n_streams - stream0 < (uint32_t)S ? p.n_streams - stream0 : (uint32_t)S;
-  const bool owner = lane < n_mine;  // lane == stream slot it owns (folded state, any-match word, hand-off row)
-  zero_final_rows(p, stream0, n_mine, lane);
-  constexpr uint32_t NLOAD = (S + 15) / 16;  // wave-loads per window refill (16 streams x 64 bytes each)
-  auto load_win = [&](uint32_t chunk, uint32_t (&o)[NLOAD][4]) {
-#pragma unroll
-    for (uint32_t g = 0; g < NLOAD; g++) {
-      const uint32_t slot = g * 16u + (lane >> 2), part = lane & 3u;
-      const bool have = slot < n_mine;
-      const uint8_t* bp = p.bytes + (size_t)(stream0 + (have ? slot : 0)) * p.stride;
-      const uint32_t off = chunk * 64u + part * 16u;
-      uint32_t v[4] = {0, 0, 0, 0};
-      if (have) {
-        if ((reinterpret_cast<uintptr_t>(bp + off) & 15u) == 0 && off + 16u <= p.stream_len) {
-          const uint4 q = *reinterpret_cast<const uint4*>(bp + off);
-          v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-        } else {
-#pragma unroll
-          for (int w4 = 0; w4 < 4; w4++)
-            for (uint32_t b = 0; b < 4; b++)
-              if (off + 4u * w4 + b < p.stream_len) v[w4] |= (uint32_t)bp[off + 4u * w4 + b] << (8u * b);
-        }
-      }
-#pragma unroll
-      for (int w4 = 0; w4 < 4; w4++) o[g][w4] = v[w4];
-    }
-  };
-  for (uint32_t w = lane; w < L::WAVE_WORDS; w += 64u) win0[w] = 0u;
-  uint32_t nxt[NLOAD][4];
-  load_win(0, nxt);
-  wave_sync();
-  auto refill = [&](uint32_t k) {  // k multiple of 64: bytes -> classes on the way into the windows, next chunk requested
-    wave_sync();
-#pragma unroll
-    for (uint32_t g = 0; g < NLOAD; g++) {
-      const uint32_t slot = g * 16u + (lane >> 2), part = lane & 3u;
-      if (slot < n_mine) {
-        uint32_t* win = win0 + slot * L::WSTR + part * 4u;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const uint32_t v = nxt[g][q];
-          win[q] = (uint32_t)cmap[v & 0xFFu] | ((uint32_t)cmap[(v >> 8) & 0xFFu] << 8) |
-                   ((uint32_t)cmap[(v >> 16) & 0xFFu] << 16) | ((uint32_t)cmap[v >> 24] << 24);
-        }
-      }
-    }
-    load_win((k >> 6) + 1u, nxt);
-    wave_sync();
-  };
-  auto stash_next_first = [&]() {  // class of the next chunk's first byte behind the window (look-ahead at byte 63)
-#pragma unroll
-    for (uint32_t g = 0; g < NLOAD; g++) {
-      const uint32_t slot = g * 16u + (lane >> 2);
-      if ((lane & 3u) == 0u && slot < n_mine) win0[slot * L::WSTR + 16u] = cmap[nxt[g][0] & 0xFFu];
-    }
-  };
-  auto store_anymatch = [&](uint32_t word) {
-    wave_sync();
-    if (owner) {
-      p.anymatch[(size_t)(stream0 + lane) * p.anymatch_stride + word] = amw[lane];
-      amw[lane] = 0u;
-    }
-    wave_sync();
-  };
-
-  // ---- the wave's state -------------------------------------------------------------------------------------------
-  uint32_t e = owner ? ((p.state0_entry & RXE_ACCEPT) | (lane << SID_SHIFT)) : FREE;  // FPGA.v:134-147: {state 0} per stream
-  uint32_t cwl = 0, cwn = 0;   // byte classes of the lane's stream: current / next group of four passes
-  uint32_t ocw = 0, ocn = 0;   // the same for the stream the lane OWNS
-  uint2 x = make_uint2(0u, 0u);
-  uint64_t macc = wballot(e & ACC);
-  bool spilled = false;
-  const uint32_t n_consume = p.n_consume < p.n_passes ? p.n_consume : p.n_passes;
-  auto gather = [&](uint32_t cn) {
-    return *reinterpret_cast<const uint2*>(regidx + (__umul24(e & RXE_TGT_MASK, ncls8) + (cn << 3)));
-  };
-  auto pulses = [&](uint32_t k) {  // accept pulses of S_k (FPGA.v:210-226); rare
-    const bool acc = (e & ACC) != 0u;
-    uint32_t dummy = 0;
-    emit_events(p, acc, e & RXE_TGT_MASK, stream0 + ((e >> SID_SHIFT) & 63u), k, lane, dummy);
-    if (acc) atomicOr(&amw[(e >> SID_SHIFT) & 63u], 1u << (k & 31u));
-  };
-
-  // everything that needs a lane of its own.  e_in / cw_in / cwn_in: the lanes as they were when the pass began
-  auto slow = [&](uint32_t k, uint32_t xf, uint32_t xs, uint32_t vA, uint32_t e_in) {
-    const uint32_t cw_in = cwl, cwn_in = cwn;
-    bool full = false;
-    // (1) candidates that are new by construction — a target next to a surviving state, the folded state's single
-    //     target — all at once: record (entry, class words) into the scratch at the candidate's rank, free lanes read theirs
-    const bool ca = (xf & RXR_EXTRA) != 0u;
-    const bool cb = (vA & (RXE_INLINE | RXE_MAYDUP | RXE_PIN)) == RXE_INLINE;
-    const uint64_t ma = wballot(ca), mb = wballot(cb);
-    const uint32_t na = (uint32_t)__popcll(ma), n = na + (uint32_t)__popcll(mb);
-    if (n > 64u) {
-      full = true;  // more candidates than the scratch (and the wave) can hold
-    } else if (n) {
-      if (ca) {
-        const uint32_t r = rank_below(ma);
-        scr_v[r] = (xs & KEEP) | (e_in & SID_MASK);
-        scr_c[r] = cw_in;
-        scr_n[r] = cwn_in;
-      }
-      if (cb) {
-        const uint32_t r = rank_below_plus(mb, na);
-        scr_v[r] = (vA & KEEP) | (lane << SID_SHIFT);
-        scr_c[r] = ocw;
-        scr_n[r] = ocn;
-      }
-      wave_sync();
-      const bool fr = (e & RXE_TGT_MASK) == FREE;
-      const uint64_t mf = wballot(fr);
-      const uint32_t f = rank_below(mf);
-      if (fr && f < n) {
-        e = scr_v[f];
-        cwl = scr_c[f];
-        cwn = scr_n[f];
-      }
-      if (n > (uint32_t)__popcll(mf)) full = true;
-      wave_sync();
-    }
-    // (2) one at a time: targets that may already be in the set, multi-target rows
-    auto place = [&](uint32_t cand, uint32_t ccw, uint32_t ccn, bool check) {  // all wave-uniform
-      if (check && wballot(((e ^ cand) & KEY) == 0u)) return;
-      const uint64_t mf = wballot((e & RXE_TGT_MASK) == FREE);
-      if (mf == 0ull) { full = true; return; }
-      if (lane == (uint32_t)__builtin_ctzll(mf)) { e = cand; cwl = ccw; cwn = ccn; }
-    };
-    auto place_list = [&](uint32_t off, uint32_t sidbits, uint32_t ccw, uint32_t ccn) {
-      const uint32_t cnt = ovf[off];
-      for (uint32_t j0 = 0; j0 < cnt; j0 += 64u) {
-        const uint32_t mine = j0 + lane < cnt ? ovf[off + 1u + j0 + lane] : 0u;
-        const uint32_t lim = cnt - j0 < 64u ? cnt - j0 : 64u;
-        for (uint32_t j = 0; j < lim; j++) {
-          const uint32_t tw = bcast(mine, j);
-          if (!(tw & RXE_PIN)) place((tw & KEEP) | sidbits, ccw, ccn, (tw & RXE_MAYDUP) != 0u);
-        }
-      }
-    };
-    uint64_t md = wballot(xf & RXR_DUPC);
-    while (md) {
-      const uint32_t src = (uint32_t)__builtin_ctzll(md);
-      md &= md - 1ull;
-      place((bcast(xs, src) & KEEP) | (bcast(e_in, src) & SID_MASK), bcast(cw_in, src), bcast(cwn_in, src), true);
-    }
-    uint64_t mo = wballot(xf & RXR_OVFL);
-    while (mo) {
-      const uint32_t src = (uint32_t)__builtin_ctzll(mo);
-      mo &= mo - 1ull;
-      place_list(bcast(xs, src) & RXE_TGT_MASK, bcast(e_in, src) & SID_MASK, bcast(cw_in, src), bcast(cwn_in, src));
-    }
-    uint64_t mq = wballot((vA & (RXE_INLINE | RXE_MAYDUP)) == (RXE_INLINE | RXE_MAYDUP) || (vA & RXE_OVF));
-    while (mq) {
-      const uint32_t src = (uint32_t)__builtin_ctzll(mq);
-      mq &= mq - 1ull;
-      const uint32_t v = bcast(vA, src), ccw = bcast(ocw, src), ccn = bcast(ocn, src);
-      if (v & RXE_OVF) place_list(v & RXE_TGT_MASK, src << SID_SHIFT, ccw, ccn);
-      else if (!(v & RXE_PIN)) place((v & KEEP) | (src << SID_SHIFT), ccw, ccn, true);
-    }
-    if (__builtin_expect(full, 0)) {
-      // more entries than lanes: hand ALL of this wave's streams (S_k, k) to the wave kernel
-      unsigned long long b = 0;
-      if (lane == 0) b = atomicAdd(p.spill_count, (unsigned long long)n_mine);
-      const uint32_t slot_base = bcast((uint32_t)b, 0);
-      wave_sync();
-      if (owner) {
-        const uint32_t slot = slot_base + lane;
-        slotw[lane] = slot;
-        p.spill_streams[slot] = stream0 + lane;
-        p.spill_k[slot] = k;
-        if (p.anymatch) p.anymatch[(size_t)(stream0 + lane) * p.anymatch_stride + (k >> 5)] = amw[lane];
-        uint32_t* row = p.spill_rows + (size_t)slot * p.nw64x2;
-        for (uint32_t w = 0; w < p.nw64x2; w++) row[w] = 0u;
-        if (k >= 1u) row[p.pin_state >> 5] = 1u << (p.pin_state & 31u);  // S_k holds the folded state
-      }
-      __threadfence();
-      wave_sync();
-      if ((e_in & RXE_TGT_MASK) != FREE) {
-        const uint32_t sq = e_in & RXE_TGT_MASK;
-        uint32_t* row = p.spill_rows + (size_t)slotw[(e_in >> SID_SHIFT) & 63u] * p.nw64x2;
-        atomicOr(&row[sq >> 5], 1u << (sq & 31u));
-      }
-      spilled = true;
-    }
-  };
-
-  uint32_t k = 0;
-  while (k < n_consume && !spilled) {  // k is a multiple of 64: next window of every stream
-    refill(k);
-    {
-      const uint32_t sid = (e >> SID_SHIFT) & 63u;
-      cwl = win0[sid * L::WSTR];
-      cwn = win0[sid * L::WSTR + 1u];
-      if (owner) { ocw = win0[lane * L::WSTR]; ocn = win0[lane * L::WSTR + 1u]; }
-      if (k == 0u) x = gather(cwl & 0xFFu);  // the words for pass 0
-    }
-    const uint32_t kend = n_consume - k < 64u ? n_consume : k + 64u;
-#pragma unroll 1
-    for (; k < kend; k++) {
-      const uint32_t kk = k & 63u, sh = 8u * (k & 3u);
-      if ((k & 3u) == 0u && kk != 0u) {  // next group of four passes: class words move up, the group after is fetched
-        const uint32_t sid = (e >> SID_SHIFT) & 63u;
-        cwl = cwn;
-        cwn = win0[sid * L::WSTR + (kk >> 2) + 1u];
-        if (owner) { ocw = ocn; ocn = win0[lane * L::WSTR + (kk >> 2) + 1u]; }
-      }
-      const bool more = k + 1u < n_consume;
-      // what the folded `.*` state emits in this pass (owner lanes; none in pass 0), reduced to the targets that
-      // survive the next byte — the full slice at the stream's last byte, whose sets are reported
-      uint32_t vA = 0u;
-      if (k >= 1u && owner) {
-        const unsigned long long o64 = ((unsigned long long)ocn << 32) | ocw;
-        const uint32_t c0 = (uint32_t)(o64 >> sh) & 0xFFu;
-        const uint32_t c1 = more ? (uint32_t)(o64 >> (sh + 8u)) & 0xFFu : ncls;
-        vA = pintab[__umul24(c0, p.pin_cols) + c1];
-      }
-      if (__builtin_expect(macc != 0ull, 0)) pulses(k);
-      const uint32_t xf = x.x, xs = x.y, e_in = e;
-      e = (xf & keepf) | (e & SID_MASK);  // every lane's in-place update, precomputed (RXR_ACC sits on RXE_ACCEPT's bit)
-      const uint64_t need = wballot((int)xf < 0), mp = wballot(vA != 0u);
-      if (__builtin_expect((need | mp) != 0ull, 0)) {
-        slow(k, xf, xs, vA, e_in);
-        if (spilled) break;
-      }
-      const unsigned long long c64 = ((unsigned long long)cwn << 32) | cwl;
-      x = gather((uint32_t)(c64 >> (sh + 8u)) & 0xFFu);  // the lane's slice for pass k+1 (a wasted load after the last byte)
-      macc = wballot(e & ACC);
-      if (p.anymatch && (k & 31u) == 31u) store_anymatch(k >> 5);
-      if (kk == 32u) stash_next_first();
-    }
-  }
-  if (!spilled) {
-    bool unsaved = (k & 31u) != 0u;
-    if (k < p.n_passes) {  // RX_MODE_FULL: pass N only looks for accept states
-      if (macc != 0ull) pulses(k);
-      k++;
-      unsaved = true;
-    }
-    if (p.anymatch && unsaved) store_anymatch((k - 1u) >> 5);
-    // final active sets: the rows were zeroed at the start of this kernel
-    if (p.final_active) {
-      if ((e & RXE_TGT_MASK) != FREE) {
-        const uint32_t sq = e & RXE_TGT_MASK;
-        uint32_t* row = p.final_active + (size_t)(stream0 + ((e >> SID_SHIFT) & 63u)) * p.nw64x2;
-        atomicOr(&row[sq >> 5], 1u << (sq & 31u));
-      }
-      if (owner && n_consume >= 1u)
-        atomicOr(&p.final_active[(size_t)(stream0 + lane) * p.nw64x2 + (p.pin_state >> 5)], 1u << (p.pin_state & 31u));
-    }
-  }
-}
-
 }  // namespace
 
 // -------------------------------------------------------------------------------------------------
@@ -2187,7 +1879,7 @@ int rx_pick_launch(uint32_t kernel, uint32_t size, uint32_t n_streams, int cu_co
   cfg->lds_per_cu = lds_per_cu;
   if (kernel == RX_KERNEL_AUTO) kernel = RX_KERNEL_SYM_PACK;  // fastest parity-checked kernel
   if (kernel != RX_KERNEL_CSR_WAVE && kernel != RX_KERNEL_SYM_WAVE && kernel != RX_KERNEL_SYM_GROUP &&
-      kernel != RX_KERNEL_SYM_PACK && kernel != RX_KERNEL_DFA && kernel != RX_KERNEL_SYM_REG && kernel != RX_KERNEL_SYM_RPACK)
+      kernel != RX_KERNEL_SYM_PACK && kernel != RX_KERNEL_DFA && kernel != RX_KERNEL_SYM_REG)
     return RX_EINVAL;
   const uint32_t nw32 = (size + 31u) / 32u;
   p->nw32 = nw32;
@@ -2294,18 +1986,6 @@ static int launch_fold(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s,
   return launch_one(rx_sym_pack_kernel<S, false, false, false, true>, p, g, wpb * 64u, lds, s);
 }
 
-template <int S>
-static int launch_rpack(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s) {
-  using L = RPackLayout<S>;
-  const uint32_t waves = (p.n_streams + S - 1) / S;
-  const uint32_t fixed = 64u + p.n_classes * p.pin_cols;
-  const size_t lds_cu = cfg.lds_per_cu ? cfg.lds_per_cu : 160u * 1024u;
-  uint32_t wpb = 8;  // the block shares one copy of the folding table; small batches take smaller blocks to reach every CU
-  while (wpb > 1 && ((size_t)(fixed + wpb * L::WAVE_WORDS) * 4u > lds_cu || (waves + wpb - 1) / wpb < 256u)) wpb >>= 1;
-  const uint32_t grid = (waves + wpb - 1) / wpb;
-  return launch_one(rx_sym_rpack_kernel<S>, p, grid ? grid : 1, wpb * 64u, (fixed + wpb * L::WAVE_WORDS) * 4u, s);
-}
-
 // returns a hipError_t value (0 = hipSuccess)
 int rx_launch(const RxParams& p, const RxLaunchCfg& cfg, void* hip_stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
@@ -2319,16 +1999,10 @@ int rx_launch(const RxParams& p, const RxLaunchCfg& cfg, void* hip_stream) {
                        : launch_one(rx_sym_wave_kernel<false>, p, cfg.grid_blocks, cfg.block_threads, cfg.lds_bytes, s);
     case RX_KERNEL_DFA:
     case RX_KERNEL_SYM_REG:
-    case RX_KERNEL_SYM_RPACK:
     case RX_KERNEL_SYM_PACK:
     case RX_KERNEL_SYM_GROUP: {
       int e;
-      if (cfg.kernel == RX_KERNEL_SYM_RPACK) {
-        if (!p.pin_tab || !p.regidx) return (int)hipErrorInvalidValue;
-        const uint32_t gl = cfg.group_lanes;
-        e = gl <= 8 ? launch_rpack<8>(p, cfg, s) : gl <= 16 ? launch_rpack<16>(p, cfg, s) : gl <= 24 ? launch_rpack<24>(p, cfg, s)
-                                                : launch_rpack<32>(p, cfg, s);
-      } else if (cfg.kernel == RX_KERNEL_SYM_REG) {  // one wavefront (= one block) per stream
+      if (cfg.kernel == RX_KERNEL_SYM_REG) {  // one wavefront (= one block) per stream
         const bool fold = cfg.fold && p.pin_tab;
         const uint32_t lds = 64u * 4u;  // the byte -> class map; the folding table is read with scalar loads
         if (cfg.reg_skip)
