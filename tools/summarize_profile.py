@@ -10,6 +10,7 @@ import csv
 import glob
 import json
 import os
+import re
 import shutil
 import sys
 
@@ -23,7 +24,8 @@ def main():
         sys.exit("no kernel_stats.csv under " + src)
     shutil.copy(stats[0], os.path.join(dst, "kernel_stats.csv"))
     rows = list(csv.DictReader(open(stats[0])))
-    match = [r for r in rows if "rx_" in r["Name"]]
+    # (AUTO's probe runs the pack kernel's statistics build <S, true, ...> a few times: never the kernel that was timed)
+    match = [r for r in rows if "rx_" in r["Name"] and not re.search(r"rx_sym_pack_kernel<\d+, true", r["Name"])]
     main_k = max(match, key=lambda r: float(r["TotalDurationNs"]))["Name"]
     short = main_k.replace("void (anonymous namespace)::", "").replace("(RxParams)", "")
     counters = collections.defaultdict(list)
