@@ -382,6 +382,23 @@ def main():
                                         "kernel_variant": sres["stats"].get("variant", "")}
         sp.close()
         del d_one
+        # small batches (a SIMD gets at most a few wavefronts): latency per pass is what counts; AUTO times the pack kernel
+        # against one wavefront per stream on the batch itself
+        small = {}
+        for sn in (64, 1024, 4096):
+            srows = make_rows(rx, "T", 0, sn, sl, traces)
+            d_s = torch.from_numpy(srows).to(dev)
+            bp = rx.Plan(nfa, sn, sl, **common)
+            bp.set_device_input(d_s.data_ptr(), sn, sl, sl, keepalive=d_s)
+            time_kernel(bp, 2)
+            bavg, _, _ = time_kernel(bp, 5)
+            bres = bp.download()
+            small[f"{sn}x{sl}"] = {"kernel_ms_avg": round(bavg, 4), "gbit_s": round(8.0 * sn * sl / (bavg * 1e-3) / 1e9, 2),
+                                   "kernel": rx.host.KERNEL_NAMES[bres["stats"]["kernel_used"]],
+                                   "kernel_variant": bres["stats"].get("variant", "")}
+            bp.close()
+            del d_s
+        out["small_batches_T"] = small
 
     if a.all_kernels:
         extra = {}

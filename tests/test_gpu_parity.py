@@ -162,6 +162,51 @@ def test_ragged_and_edge_shapes(rx, orx, automata, traces, gpu_nfas, kernels):
         check_equal(rx, orx, got, ref, ("strided", kern))
 
 
+def test_idle_stretches_are_stepped_over_exactly(rx, orx, automata, traces, gpu_nfas, kernels):
+    """The FOLD builds of the pack kernel and the skipping build of the register kernel step over passes in which nothing is
+    active.  Streams that are quiet except for short bursts planted around every boundary the skipping logic knows (the
+    32-pass any-match word, the 64-byte window, the 256-byte chunk, the stream's first and last bytes) must give exactly
+    the oracle's events, any-match bitmap, counters and final sets — on snort_16 (folded `.*` state), on a compiled automaton
+    and on one without such a state (an empty set then stays empty to the end of the stream)."""
+    hi = traces[("snort_16", "hi")]
+    rng = np.random.default_rng(20261004)
+    compiled = rx.Nfa.compile([b"needle", b"ab+c", b"x[0-9]*y", b"zz"])
+    cases = [("snort_16", gpu_nfas["snort_16"], automata["snort_16"], [hi[o:o + 14] for o in (100, 3000, 50000, 120000, 199000)]),
+             ("compiled", compiled, (compiled.words, compiled.size),
+              [np.frombuffer(b, np.uint8) for b in (b"needle", b"abbbc", b"x0123y", b"zz", b"need", b"xab9y")])]
+    marks = (0, 1, 29, 30, 31, 32, 33, 61, 62, 63, 64, 65, 126, 127, 128, 250, 254, 255, 256, 257, 510, 511, 512, 513, 1020, 1023, 1024, 1025)
+    for name, nfa, (W, size), bursts in cases:
+        for sl in (70, 300, 1500, 2111):
+            for ns in (1, 3, 70):
+                rows = np.full((ns, sl), 0x7E if name == "snort_16" else 0x2E, np.uint8)   # '~' / '.': starts nothing
+                for s in range(ns):
+                    if ns > 3 and s % 7 == 0:
+                        continue                                    # quiet from the first byte to the last
+                    picks = rng.choice(len(marks), size=int(rng.integers(1, 6)), replace=False)
+                    for m in [marks[i] for i in picks] + ([sl - 5, sl - 1] if s % 3 == 1 else []):
+                        b = bursts[int(rng.integers(len(bursts)))]
+                        if 0 <= m < sl:
+                            n = min(len(b), sl - m)
+                            rows[s, m:m + n] = b[:n]
+                for mode in (rx.MODE_FULL, rx.MODE_TB_COMPAT):
+                    ref = orx.match_batch(W, size, rows, mode=mode, want_match_count=True)
+                    if name == "compiled" and ns == 70 and sl == 2111:
+                        assert ref["n_events"] > 20
+                    for kern in kernels:
+                        got = rx.match(nfa, rows, mode=mode, want_match_count=True, **kern)
+                        check_equal(rx, orx, got, ref, (name, sl, ns, mode, kern), stats=False)
+    # no folded state at all: after the first bytes nothing is active, and nothing ever will be
+    W, size = kat_ab()
+    nfa = rx.Nfa.from_words(W)
+    rows = np.full((5, 1200), 0x71, np.uint8)
+    rows[1, :2] = (0x61, 0x62)
+    rows[3, 700:702] = (0x61, 0x62)
+    ref = orx.match_batch(W, size, rows, want_match_count=True)
+    for kern in kernels:
+        got = rx.match(nfa, rows, want_match_count=True, **kern)
+        check_equal(rx, orx, got, ref, ("ab", kern), stats=False)
+
+
 def test_device_input_unaligned(rx, orx, automata, traces, gpu_nfas, kernels):
     """rx_plan_set_device_input with a caller-owned HBM buffer whose rows are NOT 4-byte aligned."""
     torch = pytest.importorskip("torch")
