@@ -117,8 +117,12 @@ enum {
                              of the same shape) the plan runs the pack kernel's statistics build over a corner of
                              it (<= 512 streams x <= 1 KB; this synchronises the stream) and picks
                              RX_KERNEL_SYM_PACK — streams per wavefront ~ 33 / (list entries per stream), look-ahead
-                             pruning of multi-target rows when it removes >= 10 % of the entries — or, when even
-                             the long-list form of the pack kernel hands streams off, RX_KERNEL_SYM_WAVE         */
+                             pruning of multi-target rows when it removes >= 10 % of the entries, the FOLD build
+                             (always-on `.*` state out of the lists, idle passes stepped over) when that leaves the
+                             lists nearly empty — or, when even the long-list form of the pack kernel hands streams
+                             off, RX_KERNEL_SYM_WAVE.  Batches of at most 16 wavefronts per SIMD (one stream each):
+                             the pack kernel's choice and the two builds of RX_KERNEL_SYM_REG run the batch once,
+                             timed, and the fastest is taken; up to 4 streams: always RX_KERNEL_SYM_REG            */
   RX_KERNEL_CSR_WAVE = 1, /* wavefront-per-stream over the state-major CSR exactly as loaded         */
   RX_KERNEL_SYM_WAVE = 2, /* wavefront-per-stream over the per-(state,symbol) slice index            */
   RX_KERNEL_SYM_GROUP = 3, /* G lanes per stream (64/G streams per wavefront), slice index;
@@ -136,10 +140,11 @@ enum {
   RX_KERNEL_SYM_REG = 6   /* one wavefront per stream, the active set register-resident (one state per lane, updated
                              in place: no LDS list, no filter), the always-on `.*` state folded out when the automaton
                              has one: the kernel for FEW LONG streams — the reference's own run is one lock-step pair
-                             (testbench_BLK_Mem.sv:49-87).  RX_KERNEL_AUTO picks it for up to 4 streams from reset, and for batches of up to 16
-                             wavefronts per SIMD when a timed trial says so;
-                             more than 64 active states: hand-off to RX_KERNEL_SYM_WAVE.  With collect_stats or a
-                             caller-supplied start set RX_KERNEL_SYM_WAVE runs instead.                      */
+                             (testbench_BLK_Mem.sv:49-87) — and for small batches, where the latency of a pass is
+                             what counts (see RX_KERNEL_AUTO).  A second build steps over groups of passes in which no
+                             state is active (RX_OPT_REG_NO_SKIP selects the plain one).  More than 64 active states:
+                             hand-off to RX_KERNEL_SYM_WAVE.  With collect_stats or a caller-supplied start set
+                             RX_KERNEL_SYM_WAVE runs instead.                                                  */
 };
 
 typedef struct rx_opts {

@@ -5,16 +5,21 @@
 // (FPGA.v:744-765); here the active set is a compacted list per stream, so work is proportional
 // to |S_k|, and thousands of independent streams are resident at once.
 //
-// Five kernels, one result (tests/test_gpu_parity.py compares every one of them with the oracle):
+// Six kernels, one result (tests/test_gpu_parity.py compares every one of them with the oracle):
 //   rx_csr_wave_kernel   ONE WAVEFRONT OWNS ONE INPUT STREAM and reads the state-major CSR exactly as the .coe holds
 //                        it (row_ptr pair, then the whole row, as FPGA.v:166-207 / :227-714 do): long rows are swept
 //                        by all 64 lanes (256 B coalesced per load), short rows one lane per row.  North-star form.
 //   rx_sym_wave_kernel   one wavefront per stream over the load-time slice index: one u32 per (state, byte) that
 //                        holds "the current byte's slice" of that row (rx_internal.hpp).  Also the kernel that
-//                        finishes streams the three kernels below hand off (resume mode).
+//                        finishes streams the kernels below hand off (resume mode).
 //   rx_sym_group_kernel  G lanes per stream, 64/G streams per wavefront (static lane groups).
 //   rx_sym_pack_kernel   S streams per wavefront, the 64 lanes assigned dynamically to one wave-wide list of
 //                        (stream, state) entries — the throughput kernel RX_KERNEL_AUTO normally picks.
+//                        FOLD builds keep the always-on `.*` state out of the lists and step over the passes in which
+//                        nothing happens to any of the wave's streams; PRUNE builds insert only what survives the next byte.
+//   rx_sym_reg_kernel    one wavefront per stream, the active set in a VGPR (one state per lane, updated in place from a
+//                        precomputed index): the shortest pass — few long streams (the reference's own run) and small
+//                        batches.  A second build steps over groups of passes in which no state is active.
 //   rx_dfa_kernel        one LANE per stream over a lazily built subset-construction cache (opt-in).
 // Common to the two wave-per-stream kernels:
 //   * per-stream state lives in that wave's private LDS slice: two size-bit bitmasks (dedup
@@ -1609,8 +1614,8 @@ __global__ void __launch_bounds__(256) rx_dfa_kernel(const RxParams p) {
 // Kernel 6: register-resident active set, one wavefront per stream (few long streams)
 // =================================================================================================
 // The reference's own run is ONE lock-step pair of streams (testbench_BLK_Mem.sv:49-87): a single dependency chain
-// per stream, so what counts is the latency of a pass — and a lone wavefront pays ~10 cycles for EVERY instruction it
-// issues (measured: 45 instructions per pass = 500 cycles with the gather hitting L1) and more for a taken branch.
+// per stream, so what counts is the latency of a pass — a lone wavefront issues in order at ~5 cycles per instruction,
+// an L1 hit costs it ~200 cycles, a taken branch more than a straight line (DESIGN.md 3.3 has the measurements).
 // So the active set never leaves the registers and the common pass is a dozen straight-line instructions:
 //   * lane L holds at most one state id in a VGPR; a free lane holds the id `size`, whose row in the index is empty
 //     (accept states have empty rows anyway), so every lane gathers unconditionally — no EXEC masking, no branch;
@@ -1623,8 +1628,10 @@ __global__ void __launch_bounds__(256) rx_dfa_kernel(const RxParams p) {
 //   * which lanes hold an accept state is a flag bit of the fast word (pulses are rare);
 //   * no LDS list, no filter, no atomics.  What needs a lane of its own — a target next to a surviving state, a target
 //     that a second active state could also reach (RXE_MAYDUP: compared against all lanes at once), the targets of
-//     multi-target rows, the folded state's targets — is flagged in the fast word and goes through a short scalar loop
-//     (v_readlane, first free lane, v_writelane): about every second pass on the busier shipped trace.
+//     multi-target rows, the folded state's targets — is flagged in the fast word and placed by scalar code (one single
+//     target: a straight-line path; else loops over v_readlane / first free lane).  Single targets get one byte of
+//     look-ahead (RxParams::reg_tmask): one that has no edge on the next byte's class (mod 8) is not placed at all —
+//     about every third pass of the busier shipped trace places something, every second would without it.
 // More than 64 active states: the stream is handed to the wave kernel (resume mode) like in the group / pack kernels.
 // SKIP: groups of four passes in which no lane holds a state and the folded state emits nothing are stepped over (the
 // quieter shipped trace: 63 % of all passes; uniform bytes: nearly all).  A build of its own because the test, three
