@@ -223,6 +223,18 @@ typedef struct rx_result {
   size_t anymatch_stride;    /* in u32 words, >= ceil(n_passes/32)                        */
   uint64_t* final_active;    /* [n_streams][ceil(size/64)]: S after the last pass's byte  */
   rx_stats stats;            /* out */
+  /* The same final sets as compact lists (rx_plan_run only; the plan must have been created with want_final): the states of
+   * stream s are final_states[final_off[s] .. final_off[s] + final_cnt[s]), ascending.  The bitmask rows are 1.2 KB per
+   * stream for snort_16 whatever they hold — 90 % of what a call downloads; the lists are ~12 bytes + 4 per active state.
+   * All three arrays or none; final_active may be NULL then.  A caller whose struct_size ends before these fields gets rows. */
+  uint32_t* final_states;    /* [final_states_cap] */
+  uint32_t* final_off;       /* [n_streams] */
+  uint32_t* final_cnt;       /* [n_streams] */
+  size_t final_states_cap;
+  size_t n_final_states;     /* out: entries written to final_states */
+  uint32_t final_states_overflow; /* out: 1 if the sets did not fit final_states_cap (final_cnt is exact, final_off then
+                                     names only the part that was written) */
+  uint32_t reserved0;
 } rx_result;
 
 /* ---- one-shot match over host buffers ---------------------------------------------------- */

@@ -364,6 +364,10 @@ struct rx_plan {
   unsigned long long* d_mct = nullptr;
   uint32_t* d_am = nullptr;
   uint32_t* d_final = nullptr;
+  // rx_plan_run, compact final sets (on request): states per block of streams, offset / count per stream
+  uint32_t* d_fstates = nullptr;
+  uint32_t *d_foff = nullptr, *d_fcnt = nullptr;
+  size_t fstates_cap = 0;
   uint32_t* d_init = nullptr;
   bool have_init = false;             // start sets belong to ONE batch: every new input clears the flag
   std::vector<uint64_t> init_stage;   // host staging of the caller's start sets (tail bits masked)
@@ -490,6 +494,9 @@ extern "C" void rx_plan_free(rx_plan* p) {
   (void)hipFree(p->d_mc);
   (void)hipFree(p->d_am);
   (void)hipFree(p->d_final);
+  (void)hipFree(p->d_fstates);
+  (void)hipFree(p->d_foff);
+  (void)hipFree(p->d_fcnt);
   (void)hipFree(p->d_init);
   (void)hipFree(p->d_spill_streams);
   (void)hipFree(p->d_spill_k);
@@ -1246,6 +1253,23 @@ static int plan_run(rx_plan* p, const uint8_t* bytes, size_t n_streams, size_t s
   const uint32_t size = h.size;
   const size_t nw64 = ((size_t)size + 63) / 64, set_words = 16 + (size_t)size;
   if ((res->match_count && !p->want_mc) || (res->anymatch && !p->want_am) || (res->final_active && !p->want_final)) return RX_ESTATE;
+  const bool compact = res->final_states || res->final_off || res->final_cnt;
+  if (compact) {
+    if (!res->final_states || !res->final_off || !res->final_cnt || res->final_states_cap == 0) return RX_EINVAL;
+    if (!p->want_final) return RX_ESTATE;
+    if (res->final_states_cap > 0xFFFFFFFFull) return RX_EINVAL;
+    if (res->final_states_cap > p->fstates_cap) {
+      (void)hipFree(p->d_fstates);
+      p->d_fstates = nullptr;
+      p->fstates_cap = 0;
+      HIPCHK(hipMalloc((void**)&p->d_fstates, res->final_states_cap * sizeof(uint32_t)));
+      p->fstates_cap = res->final_states_cap;
+    }
+    if (!p->d_foff) {
+      HIPCHK(hipMalloc((void**)&p->d_foff, p->max_streams * sizeof(uint32_t)));
+      HIPCHK(hipMalloc((void**)&p->d_fcnt, p->max_streams * sizeof(uint32_t)));
+    }
+  }
   // input buffer of the plan, rows at a 4-byte-aligned pitch
   const size_t pitch = (stream_len + 3) & ~(size_t)3;
   const size_t need = std::max<size_t>(n_streams * pitch, 4);
@@ -1299,6 +1323,8 @@ static int plan_run(rx_plan* p, const uint8_t* bytes, size_t n_streams, size_t s
   if (p->opts.collect_stats == 2 && (per & 1)) return RX_EINVAL;
   HIPCHK(hipStreamSynchronize(p->stream));  // (the probe ran on the plan's own stream)
   const size_t ev_share = p->events_cap / n_blocks;
+  const size_t fs_share = compact ? res->final_states_cap / n_blocks : 0;
+  if (compact && fs_share == 0) return RX_EINVAL;
   const size_t am_need = (size_t)((p->params.n_passes + 31) / 32);
   if (res->anymatch && res->anymatch_stride < am_need) return RX_EINVAL;
   const bool two_tier = p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK ||
@@ -1337,6 +1363,11 @@ static int plan_run(rx_plan* p, const uint8_t* bytes, size_t n_streams, size_t s
     HIPCHK(hipEventRecord(q.k0, p->s_k));
     hipError_t e = (hipError_t)rx_launch(a, cfg, p->s_k);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    if (compact) {  // the block's share of the caller's capacity; counter = a word of the block's set nothing else uses
+      e = (hipError_t)rx_launch_final_compact(a.final_active, a.n_streams, a.nw64x2, p->d_fstates + b * fs_share, (uint32_t)fs_share,
+                                              p->d_foff + s0, p->d_fcnt + s0, q.d_set + 15, p->s_k);
+      if (e != hipSuccess) return hip_fail(e, "final-set compaction launch");
+    }
     HIPCHK(hipEventRecord(q.k1, p->s_k));
     // results of the block straight into the caller's arrays
     HIPCHK(hipStreamWaitEvent(p->s_out, q.k1, 0));
@@ -1344,6 +1375,10 @@ static int plan_run(rx_plan* p, const uint8_t* bytes, size_t n_streams, size_t s
     if (res->final_active)
       HIPCHK(hipMemcpyAsync(res->final_active + s0 * nw64, p->d_final + s0 * (size_t)a.nw64x2, cnt * nw64 * sizeof(uint64_t),
                             hipMemcpyDeviceToHost, p->s_out));
+    if (compact) {
+      HIPCHK(hipMemcpyAsync(res->final_off + s0, p->d_foff + s0, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost, p->s_out));
+      HIPCHK(hipMemcpyAsync(res->final_cnt + s0, p->d_fcnt + s0, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost, p->s_out));
+    }
     if (res->anymatch && am_need) {
       if (res->anymatch_stride == p->am_stride)  // same pitch on both sides: one flat copy (2-D copies go row by row)
         HIPCHK(hipMemcpyAsync(res->anymatch + s0 * p->am_stride, p->d_am + s0 * p->am_stride, cnt * p->am_stride * 4,
@@ -1404,6 +1439,24 @@ static int plan_run(rx_plan* p, const uint8_t* bytes, size_t n_streams, size_t s
       if (n < captured) res->events_overflow = 1u;
     }
   }
+  if (compact) {
+    // the blocks' lists, packed one behind the other in the caller's array; offsets become positions in that array
+    res->n_final_states = 0;
+    res->final_states_overflow = 0;
+    for (size_t b = 0; b < n_blocks; b++) {
+      const size_t s0 = b * per, cnt_s = std::min(per, n_streams - s0);
+      const unsigned long long needed = p->pipes[b].h_set[15];
+      const size_t have_n = (size_t)std::min<unsigned long long>(needed, fs_share);
+      if (needed > fs_share) res->final_states_overflow = 1u;
+      if (have_n)
+        HIPCHK(hipMemcpy(res->final_states + res->n_final_states, p->d_fstates + b * fs_share, have_n * sizeof(uint32_t),
+                         hipMemcpyDeviceToHost));
+      const uint32_t shift = (uint32_t)res->n_final_states;
+      if (shift)
+        for (size_t s = s0; s < s0 + cnt_s; s++) res->final_off[s] += shift;
+      res->n_final_states += have_n;
+    }
+  }
   if (p->cfg.stats) {
     st.alg_bytes = (uint64_t)p->params.n_consume * n_streams + 8 * st.sum_active + 4 * st.sum_edges +
                    (uint64_t)n_streams * ((st.n_passes + 7) / 8) + 12 * st.n_events;
@@ -1422,8 +1475,12 @@ extern "C" int rx_match(const rx_nfa* nfa, const uint8_t* bytes, size_t n_stream
   if (!nfa || !res || (!bytes && stream_len) || n_streams == 0 || stride < stream_len) return RX_EINVAL;
   if (read_opts(opts).k_base + passes_for(stream_len, RX_MODE_FULL) > (1ull << 32)) return RX_EINVAL;
   rx_plan* p = nullptr;
+  // (compact final sets: only when the caller's struct has the fields, and only on the pipelined path below)
+  const bool has_compact = result_bytes(res) >= offsetof(rx_result, final_states_overflow) + sizeof(uint32_t);
+  if (has_compact && res->final_states && init_active) return RX_EINVAL;
   int rc = rx_plan_create(nfa, opts, n_streams, stream_len, res->events ? res->events_cap : 0,
-                          res->match_count != nullptr, res->anymatch != nullptr, res->final_active != nullptr, &p);
+                          res->match_count != nullptr, res->anymatch != nullptr,
+                          res->final_active != nullptr || (has_compact && res->final_states != nullptr), &p);
   if (rc) return rc;
   auto done = [&](int code) {
     rx_plan_free(p);
@@ -1543,7 +1600,7 @@ extern "C" int rx_match_sharded(const rx_nfa* nfa, const uint8_t* bytes, size_t 
     res->stats.h2d_ms = std::max(res->stats.h2d_ms, x.r.stats.h2d_ms);
     res->stats.d2h_ms = std::max(res->stats.d2h_ms, x.r.stats.d2h_ms);
     res->stats.kernel_used = x.r.stats.kernel_used;
-    if (result_bytes(res) == sizeof(rx_result)) { res->stats.lanes_used = x.r.stats.lanes_used; res->stats.variant = x.r.stats.variant; }
+    if (result_bytes(res) >= offsetof(rx_result, stats) + sizeof(rx_stats)) { res->stats.lanes_used = x.r.stats.lanes_used; res->stats.variant = x.r.stats.variant; }
     res->stats.n_launches += x.r.stats.n_launches;
     res->stats.tb_cycles += x.r.stats.tb_cycles;  // pairs never straddle shards when every shard is even-sized
   }

@@ -153,6 +153,11 @@ struct RxLaunchCfg {
 int rx_pick_launch(uint32_t kernel, uint32_t size, uint32_t n_streams, int cu_count, size_t lds_per_cu,
                    RxParams* p, RxLaunchCfg* cfg);
 int rx_launch(const RxParams& p, const RxLaunchCfg& cfg, void* hip_stream);
+// Final sets as compact lists: rows[n_streams][row_words] (bitmask rows as the kernels leave them) -> per stream its states
+// in ascending order at states[off[s] .. off[s] + cnt[s]); off is relative to `states`; *counter (zero before the launch)
+// ends as the number of entries the sets need, entries beyond `cap` are not written.
+int rx_launch_final_compact(const uint32_t* rows, uint32_t n_streams, uint32_t row_words, uint32_t* states, uint32_t cap,
+                            uint32_t* off, uint32_t* cnt, unsigned long long* counter, void* hip_stream);
 
 // ---- host-side automaton (rx_host.cpp; no HIP in here) ---------------------------------------
 struct RxHostNfa {

@@ -49,7 +49,10 @@ class _Result(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("events_overflow", C.c_uint32), ("events", C.c_void_p),
                 ("events_cap", C.c_size_t), ("n_events", C.c_size_t), ("match_count", C.c_void_p),
                 ("match_count_total", C.c_void_p), ("anymatch", C.c_void_p), ("anymatch_stride", C.c_size_t),
-                ("final_active", C.c_void_p), ("stats", _Stats)]
+                ("final_active", C.c_void_p), ("stats", _Stats),
+                ("final_states", C.c_void_p), ("final_off", C.c_void_p), ("final_cnt", C.c_void_p),
+                ("final_states_cap", C.c_size_t), ("n_final_states", C.c_size_t), ("final_states_overflow", C.c_uint32),
+                ("reserved0", C.c_uint32)]
 
 
 class _Info(C.Structure):
@@ -266,14 +269,18 @@ class _Out:
     """Caller-allocated output arrays for one rx_result."""
 
     def __init__(self, nfa, n_streams, stream_len, mode, events_cap, want_match_count, want_total, want_anymatch,
-                 want_final):
+                 want_final, compact_final=0):
         self.npass = n_passes(stream_len, mode)
         self.ev = np.zeros(max(events_cap, 1), dtype=EVENT_DT) if events_cap else None
         self.mc = np.zeros((n_streams, nfa.size), np.uint32) if want_match_count else None
         self.tot = np.zeros(nfa.size, np.uint64) if want_total else None
         self.am_stride = max((self.npass + 31) // 32, 1)
         self.am = np.zeros((n_streams, self.am_stride), np.uint32) if want_anymatch else None
-        self.fin = np.zeros((n_streams, nfa.nw64), np.uint64) if want_final else None
+        # compact_final = capacity (entries) of the list form of the final sets (rx_plan_run); the bitmask rows are then left out
+        self.fin = np.zeros((n_streams, nfa.nw64), np.uint64) if (want_final and not compact_final) else None
+        self.fst = np.zeros(compact_final, np.uint32) if compact_final else None
+        self.foff = np.zeros(n_streams, np.uint32) if compact_final else None
+        self.fcnt = np.zeros(n_streams, np.uint32) if compact_final else None
         r = _Result()
         r.struct_size = C.sizeof(_Result)
         if self.ev is not None:
@@ -286,6 +293,9 @@ class _Out:
             r.anymatch, r.anymatch_stride = self.am.ctypes.data, self.am_stride
         if self.fin is not None:
             r.final_active = self.fin.ctypes.data
+        if self.fst is not None:
+            r.final_states, r.final_off, r.final_cnt = self.fst.ctypes.data, self.foff.ctypes.data, self.fcnt.ctypes.data
+            r.final_states_cap = compact_final
         self.r = r
 
     def as_dict(self):
@@ -293,11 +303,23 @@ class _Out:
         return dict(events=self.ev[:r.n_events] if self.ev is not None else None, n_events=int(s.n_events),
                     events_overflow=bool(r.events_overflow), match_count=self.mc, match_count_total=self.tot,
                     anymatch=self.am, final_active=self.fin,
+                    final_states=self.fst[:r.n_final_states] if self.fst is not None else None, final_off=self.foff,
+                    final_cnt=self.fcnt, final_states_overflow=bool(r.final_states_overflow),
                     stats=dict(n_passes=int(s.n_passes), n_events=int(s.n_events), sum_active=int(s.sum_active),
                                sum_edges=int(s.sum_edges), alg_bytes=int(s.alg_bytes), kernel_ms=s.kernel_ms,
                                h2d_ms=s.h2d_ms, d2h_ms=s.d2h_ms, kernel_used=int(s.kernel_used),
                                n_launches=int(s.n_launches), tb_cycles=int(s.tb_cycles), lanes_used=int(s.lanes_used),
                                variant=_variant_name(s)))
+
+
+def expand_final(res, nw64):
+    """Bitmask rows [n_streams][nw64] (uint64) from the list form of the final sets (Plan.run(compact_final=N))."""
+    off, cnt, st = res["final_off"], res["final_cnt"], res["final_states"]
+    rows = np.zeros((len(off), nw64), np.uint64)
+    for s in range(len(off)):
+        for t in st[off[s]:off[s] + cnt[s]]:
+            rows[s, int(t) >> 6] |= np.uint64(1) << np.uint64(int(t) & 63)
+    return rows
 
 
 def _variant_name(s):
@@ -416,22 +438,24 @@ class Plan:
         _chk(lib().rx_plan_download(self._h, C.byref(out.r)), "rx_plan_download")
         return out.as_dict()
 
-    def run(self, data, want_total=True, register=True):
+    def run(self, data, want_total=True, register=True, compact_final=0):
         """rx_plan_run(): host rows in, host results out in one pipelined call (upload, kernel and download of blocks of
         streams overlap).  The output arrays live as long as the plan and are page-locked once (`register`), and so is
         `data` — pass the same array again and it moves by DMA.  Returns the same dict as download(); its arrays are
-        overwritten by the next run()."""
+        overwritten by the next run().  compact_final = N: the final sets come as lists (final_states[final_off[s] ..
+        + final_cnt[s]) per stream, at most N entries in all) instead of bitmask rows — a fraction of the bytes."""
         data, stride = _as_rows(data)
         ns, sl = data.shape
-        key = (ns, sl, want_total)
+        key = (ns, sl, want_total, compact_final)
         if getattr(self, "_run_key", None) != key:
             self._release_run_buffers()
             wmc, wam, wfin = self.want
-            self._run_out = _Out(self.nfa, ns, sl, self.mode, self.events_cap, wmc, want_total, wam, wfin)
+            self._run_out = _Out(self.nfa, ns, sl, self.mode, self.events_cap, wmc, want_total, wam, wfin, compact_final)
             self._run_key = key
             self._run_reg = []
             if register:
-                for arr in (self._run_out.ev, self._run_out.mc, self._run_out.am, self._run_out.fin):
+                o = self._run_out
+                for arr in (o.ev, o.mc, o.am, o.fin, o.fst, o.foff, o.fcnt):
                     if arr is not None and arr.nbytes:
                         _chk(lib().rx_host_register(arr.ctypes.data, arr.nbytes), "rx_host_register")
                         self._run_reg.append(arr.ctypes.data)

@@ -475,6 +475,41 @@ def test_pipelined_host_to_host_run(rx, orx, automata, traces, gpu_nfas):
     assert len(ev) > 0
 
 
+def test_final_sets_as_compact_lists(rx, orx, automata, traces, gpu_nfas):
+    """rx_plan_run can return the final sets as lists (offset / count per stream into one array of states, ascending) instead
+    of bitmask rows: expanded, they are the oracle's rows — several blocks of streams, one block, a batch whose streams end
+    with many states active, a capacity that is too small (flagged, counts still exact), and rx_match's one-shot form."""
+    wl = rx.workloads
+    lo, hi = traces[("snort_16", "lo")], traces[("snort_16", "hi")]
+    W, size = automata["snort_16"]
+    nfa = gpu_nfas["snort_16"]
+    for ns, sl, cap in ((70000, 200, 1 << 20), (700, 1024, 1 << 16), (40000, 300, 1 << 20)):
+        rows = wl.trace_windows(lo, hi, ns, sl, first=5)
+        ref = orx.match_batch(W, size, rows, events_cap=1 << 22)
+        p = rx.Plan(nfa, ns, sl, device=0, events_cap=1 << 21)
+        for rep in range(2):
+            got = p.run(rows, compact_final=cap)
+            assert got["final_active"] is None and not got["final_states_overflow"]
+            assert int(got["final_cnt"].sum()) == len(got["final_states"])
+            assert np.array_equal(rx.host.expand_final(got, nfa.nw64), ref["final_active"]), (ns, sl, rep)
+            for s in (0, 1, ns // 2, ns - 1):                       # ascending within a stream
+                seg = got["final_states"][got["final_off"][s]:got["final_off"][s] + got["final_cnt"][s]]
+                assert np.all(np.diff(seg.astype(np.int64)) > 0)
+            assert got["n_events"] == ref["n_events"]
+        rows_form = p.run(rows)                                      # and the rows again on the same plan
+        assert np.array_equal(rows_form["final_active"], ref["final_active"])
+        p.close()
+    # capacity too small: flagged; the counts are still what the sets hold
+    ns, sl = 5000, 256
+    rows = wl.trace_windows(lo, hi, ns, sl)
+    ref = orx.match_batch(W, size, rows)
+    want = np.array([bin(int(w)).count("1") for w in ref["final_active"].reshape(-1)]).reshape(ns, -1).sum(axis=1)
+    p = rx.Plan(nfa, ns, sl, device=0)
+    got = p.run(rows, compact_final=1000)
+    assert got["final_states_overflow"] and np.array_equal(got["final_cnt"], want.astype(np.uint32)) and len(got["final_states"]) <= 1000
+    p.close()
+
+
 def test_events_capacity_overflow(rx, orx, automata, traces, gpu_nfas):
     W, size = automata["snort_16"]
     rows = np.stack([traces[("snort_16", "hi")][:4000]] * 8)
