@@ -350,11 +350,12 @@ def _as_rows(data):
 
 def match(nfa, data, mode=MODE_FULL, kernel=KERNEL_AUTO, device=-1, init_active=None, events_cap=1 << 20,
           want_match_count=False, want_total=True, want_anymatch=True, want_final=True, collect_stats=False,
-          k_base=0, group_lanes=0, flags=0):
-    """rx_match(): one-shot match of uint8 [n_streams, stream_len] host rows on one GPU."""
+          k_base=0, group_lanes=0, flags=0, compact_final=0):
+    """rx_match(): one-shot match of uint8 [n_streams, stream_len] host rows on one GPU.  compact_final = N: the final
+    sets as lists of at most N states in all (see Plan.run) instead of bitmask rows; streams from reset only."""
     data, stride = _as_rows(data)
     ns, sl = data.shape
-    out = _Out(nfa, ns, sl, mode, events_cap, want_match_count, want_total, want_anymatch, want_final)
+    out = _Out(nfa, ns, sl, mode, events_cap, want_match_count, want_total, want_anymatch, want_final, compact_final)
     o = _mk_opts(device, mode, kernel, None, k_base, collect_stats, group_lanes, flags)
     ia = None
     if init_active is not None:

@@ -499,6 +499,13 @@ def test_final_sets_as_compact_lists(rx, orx, automata, traces, gpu_nfas):
         rows_form = p.run(rows)                                      # and the rows again on the same plan
         assert np.array_equal(rows_form["final_active"], ref["final_active"])
         p.close()
+    # one-shot form; with a caller-supplied start set the lists are refused (that path downloads rows)
+    rows = wl.trace_windows(lo, hi, 900, 333)
+    ref = orx.match_batch(W, size, rows)
+    got = rx.match(nfa, rows, compact_final=1 << 14)
+    assert got["final_active"] is None and np.array_equal(rx.host.expand_final(got, nfa.nw64), ref["final_active"])
+    with pytest.raises(rx.RxError):
+        rx.match(nfa, rows, compact_final=1 << 14, init_active=ref["final_active"])
     # capacity too small: flagged; the counts are still what the sets hold
     ns, sl = 5000, 256
     rows = wl.trace_windows(lo, hi, ns, sl)
