@@ -223,10 +223,12 @@ typedef struct rx_result {
   size_t anymatch_stride;    /* in u32 words, >= ceil(n_passes/32)                        */
   uint64_t* final_active;    /* [n_streams][ceil(size/64)]: S after the last pass's byte  */
   rx_stats stats;            /* out */
-  /* The same final sets as compact lists (rx_plan_run only; the plan must have been created with want_final): the states of
+  /* The same final sets as compact lists (the plan must have been created with want_final): the states of
    * stream s are final_states[final_off[s] .. final_off[s] + final_cnt[s]), ascending.  The bitmask rows are 1.2 KB per
    * stream for snort_16 whatever they hold — 90 % of what a call downloads; the lists are ~12 bytes + 4 per active state.
-   * All three arrays or none; final_active may be NULL then.  A caller whose struct_size ends before these fields gets rows. */
+   * All three arrays or none; final_active may be NULL then.  rx_plan_run and rx_match from reset; rx_match with a start
+   * set, rx_match_sharded and rx_plan_download return RX_EINVAL / ignore them.  A caller whose struct_size ends before
+   * these fields gets rows. */
   uint32_t* final_states;    /* [final_states_cap] */
   uint32_t* final_off;       /* [n_streams] */
   uint32_t* final_cnt;       /* [n_streams] */

@@ -1526,6 +1526,9 @@ extern "C" int rx_match_sharded(const rx_nfa* nfa, const uint8_t* bytes, size_t 
                                 rx_result* res) {
   RX_TRY
   if (!nfa || !res || n_devices <= 0 || n_streams == 0 || stride < stream_len) return RX_EINVAL;
+  // (the list form of the final sets is per device; the sharded call returns rows)
+  if (result_bytes(res) >= offsetof(rx_result, final_states_overflow) + sizeof(uint32_t) && (res->final_states || res->final_off || res->final_cnt))
+    return RX_EINVAL;
   const int nd = (int)std::min<size_t>((size_t)n_devices, n_streams);
   const uint32_t size = nfa->h.size;
   const size_t nw64 = ((size_t)size + 63) / 64;
