@@ -737,8 +737,8 @@ static int auto_probe_pack(rx_plan* p) {
   // Always-on-state folding (automata whose state 0 enters a `.*` state on every byte): that state leaves the lists, and
   // of its targets only those that survive the next byte enter them.  The FOLD build pays a fixed price per pass for
   // the folded state's table look-ups and wins when the lists are nearly empty afterwards (measured, snort_16, one
-  // MI355X: uniform bytes 0.006 entries left per stream-byte: 65 536 streams 1 050 -> 1 430 Gbit/s, 131 072 streams
-  // 1 120 -> 2 210 Gbit/s; trace windows 1.1 left: 505 -> 476 Gbit/s, no gain) — so the probe runs it on the sample,
+  // MI355X: uniform bytes 0.006 entries left per stream-byte: 65 536 streams 1 050 -> 2 600 Gbit/s, 131 072 streams
+  // 1 120 -> 2 770 Gbit/s; trace windows 1.1 left: 505 -> 476 Gbit/s, no gain) — so the probe runs it on the sample,
   // reads how many entries were left, and takes it below 0.3 per stream-byte.  Streams per wavefront: as many as still
   // give every SIMD two wavefronts (16 ... 64).
   if (p->tab.pin_tab && !(p->opts.flags & RX_OPT_NO_FOLD) && active <= 3.0) {
