@@ -52,7 +52,9 @@ enum {
   RX_EINVAL = -1,    /* bad argument (NULL, zero size, stride < stream_len, ...) */
   RX_EIO = -2,       /* file could not be opened / read */
   RX_EFORMAT = -3,   /* .coe / .mem text is malformed */
-  RX_ENFA = -4,      /* word array is not a valid CSR automaton (row_ptr / targets / size) */
+  RX_ENFA = -4,      /* word array is not a valid CSR automaton (row_ptr / targets / size) — or size 0 was passed and
+                        more than one size fits the words (e.g. a last edge word of 0 reads like padding): pass the size,
+                        as the reference does (size_range, testbench_BLK_Mem.sv:20) */
   RX_ENOMEM = -5,    /* host or device allocation failed */
   RX_ENODEVICE = -6, /* no usable HIP device (there is NO CPU fallback) */
   RX_EHIP = -7,      /* a HIP runtime call failed; rx_last_hip_error() has the text */

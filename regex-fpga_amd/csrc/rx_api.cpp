@@ -51,7 +51,7 @@ extern "C" const char* rx_strerror(int code) {
     case RX_EINVAL: return "invalid argument";
     case RX_EIO: return "file could not be read";
     case RX_EFORMAT: return "malformed input text (.coe / .mem / regex)";
-    case RX_ENFA: return "word array is not a valid CSR automaton";
+    case RX_ENFA: return "word array is not a valid CSR automaton, or (size 0) its size cannot be inferred unambiguously: pass size";
     case RX_ENOMEM: return "out of memory";
     case RX_ENODEVICE: return "no usable HIP device (librxmatch has no CPU fallback)";
     case RX_EHIP: return "HIP runtime error (see rx_last_hip_error)";

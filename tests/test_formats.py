@@ -91,6 +91,23 @@ def test_malformed_inputs(rx, tmp_path):
     assert (n.size, n.nnz, n.n_accept) == (2, 1, 1)
 
 
+def test_ambiguous_size_is_refused_not_guessed(rx, orx):
+    """The .coe carries no state count (the testbench passes it as a parameter, testbench_BLK_Mem.sv:20).  When the last edge
+    is (symbol 0 -> state 0) its word is 0 and reads like padding, and a second size fits the words: size inference says so
+    (found by the GPU fuzzer, seed 777 case 9162) instead of picking one; with the size given the automaton loads."""
+    # 4 states: 0 --a--> 1, 1 --NUL--> 0, states 2 and 3 without edges: row_ptr 0 1 2 2 2, edges (0x61, 1) (0x00, 0).
+    # Read with size 3 the words are row_ptr 0 1 2 2, edges (0x00, 2) (0x61, 1) and one word of padding: valid as well.
+    W = np.array([0, 1, 2, 2, 2, 0x61000001, 0x00000000], np.uint32)
+    with pytest.raises(rx.RxError) as e:
+        rx.Nfa.from_words(W)
+    assert "size" in str(e.value)
+    n = rx.Nfa.from_words(W, 4)
+    assert (n.size, n.nnz) == (4, 2)
+    assert rx.Nfa.from_words(W, 3).nnz == 2          # (the other reading, when the caller says so)
+    ref = orx.match_batch(W, 4, np.frombuffer(b"a\x00a", np.uint8))
+    assert ref["stats"]["n_passes"] == 4
+
+
 def test_size_inference_rejects_garbage(rx):
     with pytest.raises(rx.RxError):
         rx.Nfa.from_words(np.array([5, 1, 2, 3], np.uint32))

@@ -44,14 +44,14 @@ def one_case(rng, trial):
         size = int(rng.integers(2, 600))
         alpha = int(rng.integers(2, 20))
         W, size = random_nfa(rng, size, max_deg=int(rng.integers(1, 30)), alphabet=alpha, dense_rows=int(rng.integers(0, 4)))
-        nfa = rx.Nfa.from_words(W)
+        nfa = rx.Nfa.from_words(W, size)  # (a last edge word of 0 — symbol 0 to state 0 — makes the size ambiguous without it)
     elif kind == 1:
         W, size = blowup_nfa(int(rng.integers(20, 400)))
-        nfa = rx.Nfa.from_words(W)
+        nfa = rx.Nfa.from_words(W, size)
         alpha = None
     elif kind == 2:
         W, size = late_blowup_nfa(int(rng.integers(20, 300)))
-        nfa = rx.Nfa.from_words(W)
+        nfa = rx.Nfa.from_words(W, size)
         alpha = None
     else:
         while True:
