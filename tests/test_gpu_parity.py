@@ -313,7 +313,7 @@ def test_random_automata(rx, orx, kernels):
         size = int(rng.integers(2, 400))
         alpha = int(rng.integers(2, 12))
         W, size = random_nfa(rng, size, max_deg=int(rng.integers(1, 20)), alphabet=alpha, dense_rows=int(rng.integers(0, 3)))
-        nfa = rx.Nfa.from_words(W)
+        nfa = rx.Nfa.from_words(W, size)
         ns, sl = int(rng.integers(1, 40)), int(rng.integers(0, 300))
         rows = rng.integers(0, alpha, size=(ns, sl), dtype=np.uint8)
         mode = int(trial & 1)
@@ -409,7 +409,7 @@ def test_pair_clock_model_on_random_automata(rx, orx):
         size = int(rng.integers(2, 60))
         alpha = int(rng.integers(2, 9))
         W, size = random_nfa(rng, size, max_deg=int(rng.integers(1, 14)), alphabet=alpha, dense_rows=int(rng.integers(0, 2)))
-        nfa = rx.Nfa.from_words(W)
+        nfa = rx.Nfa.from_words(W, size)
         n_pairs, n = int(rng.integers(1, 20)), int(rng.integers(2, 150))
         rows = rng.integers(0, alpha, size=(2 * n_pairs, n), dtype=np.uint8)
         want = sum(orx.tb_cycle(W, size, rows[2 * q], rows[2 * q + 1], n, skip_idle=bool(q & 1))["total_cycles"]
