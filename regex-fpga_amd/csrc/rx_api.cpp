@@ -86,6 +86,9 @@ struct rx_nfa {
   std::mutex mu;
   std::map<int, DevTables> dev;  // HBM copies, one per device, uploaded on first use
   std::vector<int32_t> accept_pattern;  // filled by rx_compile_patterns
+  // AUTO, batches too small for a probe: do few of the cells the register kernel would place from hold lists?  (-1: not
+  // looked at yet; the index is immutable, so the answer is computed once, under mu)
+  int few_lists = -1;
 };
 
 extern "C" int rx_nfa_from_words(const uint32_t* words, size_t nwords, uint32_t size_or_0, rx_nfa** out) {
@@ -795,13 +798,16 @@ static int auto_probe(rx_plan* p, bool reg_eligible) {
   if (rc || !reg_eligible) return rc;
   const RxHostNfa& h = p->nfa->h;
   if (p->n_streams * p->stream_len < (256u << 10)) {
-    size_t nz = 0, ov = 0;
-    if (!h.pin_tab.empty()) {
-      for (uint32_t w : h.pin_tab) { nz += w != 0u; ov += (w & RXE_OVF) != 0u; }
-    } else {
-      for (uint32_t w : h.symidx_c) { nz += w != 0u; ov += (w & RXE_OVF) != 0u; }
+    rx_nfa* n = const_cast<rx_nfa*>(p->nfa);
+    {
+      std::lock_guard<std::mutex> lk(n->mu);
+      if (n->few_lists < 0) {
+        size_t nz = 0, ov = 0;
+        for (uint32_t w : (!h.pin_tab.empty() ? h.pin_tab : h.symidx_c)) { nz += w != 0u; ov += (w & RXE_OVF) != 0u; }
+        n->few_lists = ov * 4u <= nz ? 1 : 0;
+      }
     }
-    if (ov * 4u <= nz) p->auto_kernel = RX_KERNEL_SYM_REG;
+    if (n->few_lists == 1) p->auto_kernel = RX_KERNEL_SYM_REG;
     p->auto_reg_skip = !h.pin_tab.empty();
     return RX_OK;
   }
