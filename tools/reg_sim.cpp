@@ -62,7 +62,7 @@ int main(int argc, char** argv) {
     }
     printf("states a one-special-class descriptor cannot hold: %d of %u\n", nc, size);
   }
-  unsigned long long n_empty = 0, last_empty = 0, cl1 = 0, cl2 = 0, cpass = 0, slow_la = 0, slow_la1 = 0, slow_la8 = 0, kept = 0, kept1 = 0;
+  unsigned long long hist_items[6] = {0, 0, 0, 0, 0, 0}, n_empty = 0, last_empty = 0, cl1 = 0, cl2 = 0, cpass = 0, slow_la = 0, slow_la1 = 0, slow_la8 = 0, kept = 0, kept1 = 0;
   std::vector<uint32_t> e(1, 0u);  // lanes in use (no FREE kept)
   unsigned long long slow = 0, c_extra = 0, c_dupc = 0, c_ovfl = 0, c_va_inl = 0, c_va_ovf = 0, places = 0, dupchecks = 0, act = 0, maxact = 0;
   unsigned long long p_extra = 0, p_dupc = 0, p_ovfl = 0, p_va = 0, only_va = 0, moved = 0, complexlanes = 0;
@@ -103,6 +103,7 @@ int main(int argc, char** argv) {
       for (uint32_t w : cand_nodup) keep += live(w, false), keep1 += live(w, true), keep8 += live8(w);
       for (uint32_t w : cand_dup) keep += live(w, false), keep1 += live(w, true), keep8 += live8(w);
       if (keep8 || no || vA) slow_la8++;
+      { int items = keep8 + (vA ? 1 : 0) + no; hist_items[items > 5 ? 5 : items]++; }
       if (keep || no || vA) slow_la++;
       if (keep1 || no || vA) slow_la1++;
       kept += keep; kept1 += keep1;
@@ -135,6 +136,8 @@ int main(int argc, char** argv) {
          p_ovfl / P, p_va / P, only_va / P);
   printf("per pass: EXTRA lanes %.3f DUPC lanes %.3f OVFL lanes %.3f; emissions inline %.3f list %.3f; place() calls %.3f, of them with duplicate check %.3f\n",
          c_extra / P, c_dupc / P, c_ovfl / P, c_va_inl / P, c_va_ovf / P, places / P, dupchecks / P);
+  printf("things to place per pass (single targets that survive the mod-8 look-ahead + emission + lists): 0: %.3f  1: %.3f  2: %.3f  3: %.3f  4: %.3f  5+: %.3f\n",
+         hist_items[0] / P, hist_items[1] / P, hist_items[2] / P, hist_items[3] / P, hist_items[4] / P, hist_items[5] / P);
   printf("passes after which no lane is in use: %.3f of all, the last one is pass %llu\n", n_empty / P, last_empty);
   printf("with look-ahead on single targets: passes needing placement %.3f (exact), %.3f (classes mod 8, as built), %.3f (targets with one live class only); single targets placed per pass %.3f / %.3f\n", slow_la / P, slow_la8 / P, slow_la1 / P, kept / P, kept1 / P);
   printf("lane-passes on states without a descriptor: same-action multi-class %.4f, other %.4f per pass; passes with any %.4f\n", cl1 / P, cl2 / P, cpass / P);
