@@ -117,7 +117,7 @@ enum { RX_MODE_FULL = 0, RX_MODE_TB_COMPAT = 1 };
 enum {
   RX_KERNEL_AUTO = 0,     /* probe, then choose: on the first launch for a batch (and again on every 32nd batch
                              of the same shape) the plan runs the pack kernel's statistics build over a corner of
-                             it (<= 512 streams x <= 1 KB; this synchronises the stream) and picks
+                             it (512 K stream-bytes: up to 4 KB of <= 512 streams; this synchronises the stream) and picks
                              RX_KERNEL_SYM_PACK — streams per wavefront ~ 33 / (list entries per stream), look-ahead
                              pruning of multi-target rows when it removes >= 10 % of the entries, the FOLD build
                              (always-on `.*` state out of the lists, idle passes stepped over) when that leaves the

@@ -656,8 +656,8 @@ static int ensure_spill_area(rx_plan* p, RxParams& a) {
 }
 
 // RX_KERNEL_AUTO: the fastest kernel depends on how many states are active per stream, which depends on
-// the input.  Probe: the pack kernel's statistics build over a corner of the batch (<= 512 streams x <= 1024
-// bytes, no outputs), then: small active sets -> pack kernel, larger ones -> wavefront-per-stream slice kernel.
+// the input.  Probe: the pack kernel's statistics build over a corner of the batch (512 K stream-bytes: the first <= 4096
+// bytes of <= 512 streams, no outputs), then: small active sets -> pack kernel, larger ones -> wavefront-per-stream slice kernel.
 static int auto_probe_pack(rx_plan* p) {
   p->auto_kernel = RX_KERNEL_SYM_PACK;
   p->auto_lanes = 16;
@@ -668,13 +668,17 @@ static int auto_probe_pack(rx_plan* p) {
   if (p->n_streams * p->stream_len < (256u << 10)) return RX_OK;  // tiny batch: not worth a probe
   // one run of the pack kernel with `lanes` streams per wavefront over the corner of the batch: the statistics
   // build (counters) or, with stats = false, the build that would really run (only the hand-off count is read)
+  // the sample: up to 4 KB of each stream (how many states are active grows along a stream: the first KB of 4 KB windows
+  // shows 2.5 list entries per stream-byte, the whole window 3.8), as many streams as make 512 K stream-bytes
+  const size_t sample_len = std::min<size_t>(p->stream_len, 4096);
+  const size_t sample_streams = std::min<size_t>(p->n_streams, std::max<size_t>(128, (512u << 10) / std::max<size_t>(sample_len, 1)));
   unsigned long long cnt[16];
   bool run_fold = false;  // the next run() uses the FOLD build
   auto run = [&](uint32_t lanes, bool stats, bool prune, double* spilled) -> int {
     RxParams a;
     fill_common(p, a);
-    a.n_streams = (uint32_t)std::min<size_t>(p->n_streams, 512);
-    a.stream_len = (uint32_t)std::min<size_t>(p->stream_len, 1024);
+    a.n_streams = (uint32_t)sample_streams;
+    a.stream_len = (uint32_t)sample_len;
     a.n_passes = a.stream_len + 1;
     a.n_consume = a.stream_len;
     RxLaunchCfg cfg{};
@@ -694,7 +698,7 @@ static int auto_probe_pack(rx_plan* p) {
     *spilled = (double)cnt[3] / a.n_streams;
     return RX_OK;
   };
-  const double units = (double)std::min<size_t>(p->n_streams, 512) * std::max<size_t>(std::min<size_t>(p->stream_len, 1024), 1);
+  const double units = (double)sample_streams * (double)std::max<size_t>(sample_len, 1);
   double spilled = 0;
   int rc = run(16, true, false, &spilled);
   if (rc) return rc;
