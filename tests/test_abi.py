@@ -114,3 +114,18 @@ def test_options_struct_of_an_older_caller(rx):
     o.flags = 0xFFFFFFFF                         # garbage behind the caller's struct
     p = C.c_void_p()
     assert h.lib().rx_plan_create(nfa._h, C.byref(o), 1, 4, 0, 0, 0, 0, C.byref(p)) == -1
+
+
+def test_list_form_of_final_sets_expands_to_rows(rx):
+    """host.expand_final: (offset, count, states) per stream -> the bitmask rows rx_result.final_active would hold."""
+    import numpy as np
+    res = dict(final_off=np.array([0, 2, 2, 5], np.uint32), final_cnt=np.array([2, 0, 3, 1], np.uint32),
+               final_states=np.array([1, 64, 0, 63, 130, 7], np.uint32))
+    rows = rx.host.expand_final(res, 3)
+    want = np.zeros((4, 3), np.uint64)
+    want[0, 0] = 1 << 1
+    want[0, 1] = 1 << 0
+    want[2, 0] = (1 << 0) | (1 << 63)
+    want[2, 2] = 1 << 2
+    want[3, 0] = 1 << 7
+    assert rows.dtype == np.uint64 and np.array_equal(rows, want)
