@@ -94,6 +94,12 @@ def one_case(rng, trial):
             bad = np.nonzero((got["final_active"] != ref["final_active"]).any(axis=1))[0][:8].tolist()
             return (f"MISMATCH trial {trial} kind {kind} size {size} ns {ns} sl {sl} mode {mode} kernel {kern} fields {which} "
                     f"bad final rows {bad} max_active {ref['stats']['max_active']} n_events {got['n_events']}/{ref['n_events']}")
+    if rng.integers(4) == 0:  # every fourth case also with the final sets as lists (one-shot form of rx_plan_run)
+        cap = int(max(64, np.unpackbits(ref["final_active"].view(np.uint8)).sum() + 1))
+        got = rx.match(nfa, rows, mode=mode, events_cap=CAP, compact_final=cap)
+        if got["final_states_overflow"] or not np.array_equal(rx.host.expand_final(got, nfa.nw64), ref["final_active"]) or \
+                got["n_events"] != ref["n_events"]:
+            return f"MISMATCH trial {trial} kind {kind} size {size} ns {ns} sl {sl} mode {mode}: final sets as lists (cap {cap})"
     return None
 
 
