@@ -5,7 +5,9 @@ A "step" is one pass of the hot path over one resident batch: ONE launch of the 
 `streams-per-gpu` streams x `stream-len` bytes that already sit in HBM.
 
     python bench.py                          # N=1: BASELINE configs[2], 65 536 x 1 KB, distribution T
-    python bench.py --gpus 8                 # spawns 8 ranks itself: configs[3], 131 072 x 1 KB per GPU
+    python bench.py --gpus 8                 # spawns 8 ranks itself; the SAME per-GPU shape (65 536 x 1 KB each): weak scaling
+    python bench.py --gpus N --config 3      # N = 1, 2, 4, 8: the sweep at configs[3]'s per-GPU shape (131 072 x 1 KB each;
+                                             # at N = 8 that is BASELINE configs[3] itself, 1 Mi streams)
     python bench.py --gpus 8 --config 4      # configs[4] stand-in: snort_16 on 4 KB T windows, 131 072 per GPU
     python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8   # what the driver does: same result
 
@@ -52,7 +54,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=None,
-                    help="BASELINE.json configs index; default 2 at --gpus 1, 3 at --gpus N>1")
+                    help="BASELINE.json configs index, read as the PER-GPU shape at every --gpus N (default 2: a sweep over "
+                         "N then keeps the per-GPU work fixed; --config 3 = 131 072 x 1 KB per GPU, configs[3] itself at N = 8)")
     ap.add_argument("--streams-per-gpu", type=int, default=None)
     ap.add_argument("--stream-len", type=int, default=None)
     ap.add_argument("--workload", choices=["T", "U", "R", "L"], default=None,
@@ -70,7 +73,7 @@ def parse():
                     help="nccl (= RCCL) for real multi-GPU runs; gloo only to rehearse ranks on fewer GPUs")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     a = ap.parse_args()
-    cfg = a.config if a.config is not None else (2 if a.gpus == 1 else 3)
+    cfg = a.config if a.config is not None else 2
     ns, sl, wl, desc = CONFIGS[cfg]
     a.config = cfg
     a.config_desc = desc if (a.streams_per_gpu is None and a.stream_len is None and a.workload is None) else \
@@ -218,6 +221,7 @@ def main():
     sec, ev_total, bytes_total = rx.sharding.reduce_report(dist if world > 1 else None, rdev, t1 - t0, n_events,
                                                            ns * sl)
     kavg_ms = ksum / max(nk, 1)
+    per_rank_ms = rx.sharding.gather_per_rank(dist if world > 1 else None, rdev, kavg_ms)
 
     if rank != 0:
         if world > 1:
@@ -280,6 +284,10 @@ def main():
                                                       "note": "FPGA-style whole-row bytes (1 + sum(8 + 4 deg) per pass + outputs) / "
                                                               "kernel time; this kernel reads one slice-index dword per active "
                                                               "state instead, so this is work done, not bytes moved"}},
+        # every rank's mean kernel time (rank order) and the per-GPU rate it implies: scaling efficiency can be read off one line
+        "per_rank_kernel_ms": [round(x, 4) for x in per_rank_ms],
+        "per_rank_kernel_ms_min_max": [round(min(per_rank_ms), 4), round(max(per_rank_ms), 4)],
+        "per_gpu_gbit_s": [round(8.0 * ns * sl / (x * 1e-3) / 1e9, 2) for x in per_rank_ms],
         "accept_events_per_launch": ev_total,
         "h2d_inclusive_gbit_s": round(8.0 * ns * sl / (h2d_s + kavg_ms * 1e-3) / 1e9, 3),
         "h2d_pinned_inclusive_gbit_s": round(8.0 * ns * sl / (h2d_pinned_s + kavg_ms * 1e-3) / 1e9, 3),
@@ -458,17 +466,28 @@ def main():
                                          f"oracle (oracle/rx_oracle.c), {ref['threads']} threads, {cpu_s:.2f} s wall "
                                          f"(~{cpu_s * ref['threads']:.0f} core-s)",
                                "events_match_gpu_on_sample": ok}
-        # RTL-equivalent baseline: the clock-accurate restatement of FPGA.v + Blk_Mem_tb, 1 core, no skip
-        m = 3000
+        # RTL-equivalent baseline: the clock-accurate restatement of FPGA.v + Blk_Mem_tb on the reference's
+        # OWN run — the whole shipped trace pair, every clock simulated (no idle fast-forward), 1 core — so the line carries
+        # the number the testbench prints (`Total no. cycles`, testbench_BLK_Mem.sv:84).  ~20 s for snort_16.
+        if a.workload == "R":
+            m = min(3000, sl)
+            pair = (rows[0], rows[1] if ns > 1 else rows[0])
+            what, expect = "first %d bytes of streams 0+1" % m, None
+        else:
+            m = 200000
+            pair = (traces[0][:m + 1], traces[1][:m + 1])
+            what = ("the shipped l7-filter lo+hi pair" if a.workload == "L" else "the shipped snort_16 lo+hi pair") + \
+                   ", all 199 999 passes Blk_Mem_tb runs before $finish"
+            expect = 617518104 if a.workload == "L" else 2188184738
         t = time.perf_counter()
-        cyc = orx.tb_cycle(W, size, rows[0], rows[1] if ns > 1 else rows[0], min(m, sl), skip_idle=False) if a.workload == "R" else \
-            orx.tb_cycle(W, size, traces[0], traces[1], m, skip_idle=False)
-        m = min(m, sl) if a.workload == "R" else m
+        cyc = orx.tb_cycle(W, size, pair[0], pair[1], m, skip_idle=False)
         cyc_s = time.perf_counter() - t
         out["cpu_baseline"]["rtl_model"] = {
             "kind": "clock-accurate C restatement of FPGA.v (no Verilator in the image)", "cores": 1,
-            "clocks": cyc["total_cycles"], "clocks_per_s": round(cyc["total_cycles"] / cyc_s),
-            "input_bit_s": round(2 * (m - 1) * 8 / cyc_s), "sample": f"first {m} bytes of " + ("streams 0+1" if a.workload == "R" else "the l7 lo+hi traces" if a.workload == "L" else "the snort_16 lo+hi traces")}
+            "total_cycles": cyc["total_cycles"], "total_cycles_expected": expect,
+            "clocks_per_s": round(cyc["total_cycles"] / cyc_s), "wall_s": round(cyc_s, 2),
+            "input_bit_s": round(2 * (m - 1) * 8 / cyc_s), "sample": what}
+        assert expect is None or cyc["total_cycles"] == expect, "clock model disagrees with the survey's Total no. cycles"
         assert ok, "GPU events differ from the oracle on the CPU-baseline sample"
     print(json.dumps(out))
     if world > 1:

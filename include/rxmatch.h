@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define RX_ABI_VERSION 2
+#define RX_ABI_VERSION 3
 
 /* ---- error codes ------------------------------------------------------------------------ */
 enum {
@@ -150,7 +150,8 @@ enum {
 };
 
 typedef struct rx_opts {
-  uint32_t struct_size; /* = sizeof(rx_opts); 0 is accepted as "this version"            */
+  uint32_t struct_size; /* = sizeof(rx_opts).  0 = the ABI-1 layout (everything before `flags`):
+                           what "this version" meant when 0 was introduced                */
   int32_t device;       /* HIP device ordinal; -1 = the calling thread's current device  */
   uint32_t mode;        /* RX_MODE_*                                                     */
   uint32_t kernel;      /* RX_KERNEL_*                                                   */
@@ -173,7 +174,12 @@ enum {
   RX_OPT_PROFILE_PACK = 8u, /* SYM_PACK S=16: the s_memtime-stamped diagnostic build (phase shares on stderr)     */
   RX_OPT_NO_FOLD = 16u,     /* SYM_PACK: never fold the always-on `.*` state out of the lists                     */
   RX_OPT_FORCE_FOLD = 32u,  /* SYM_PACK: fold it whenever the automaton has such a state                          */
-  RX_OPT_REG_NO_SKIP = 64u  /* SYM_REG: the build that does not step over passes in which no state is active (A/B runs) */
+  RX_OPT_REG_NO_SKIP = 64u, /* SYM_REG: the build that does not step over passes in which no state is active (A/B runs) */
+  RX_OPT_INJECT_RUN_FAULT = 128u, /* test hook: rx_plan_run fails with RX_EHIP once block 0's kernels and copies are in
+                                     flight — exercises the drain-before-error-return path                           */
+  RX_OPT_NO_PROBE = 256u    /* RX_KERNEL_AUTO never probes inside rx_plan_launch / rx_plan_run: no sample launches, no
+                               timed candidates, no stream synchronisation.  The decision is the one rx_plan_tune made
+                               for the shape, or a default (SYM_PACK, 16 streams per wavefront; SYM_REG up to 4 streams) */
 };
 
 /* One accept pulse: `state` was active and accepting in pass `k` of stream `stream`.
@@ -210,7 +216,8 @@ enum {
 
 /* All output arrays are caller-allocated and optional (NULL = not wanted). */
 typedef struct rx_result {
-  uint32_t struct_size;      /* = sizeof(rx_result); 0 accepted                           */
+  uint32_t struct_size;      /* = sizeof(rx_result); 0 = the ABI-1 layout (up to stats.tb_cycles:
+                                no lanes_used / variant, no compact final sets)           */
   uint32_t events_overflow;  /* out: 1 if n_events > events_cap (events[] holds the first
                                 events_cap in (stream,k,state) order of those captured)   */
   rx_event* events;          /* [events_cap], returned sorted by (stream, k, state)       */
@@ -271,8 +278,18 @@ int rx_plan_set_device_input(rx_plan* plan, const void* device_bytes, size_t n_s
  * batch given last; every new input (rx_plan_upload / rx_plan_set_device_input / rx_plan_run) restores reset, and so
  * does NULL. */
 int rx_plan_set_init_active(rx_plan* plan, const uint64_t* init_active);
-/* Enqueue result-reset + the match kernel on the plan's stream, bracketed by hipEvents. */
+/* Enqueue result-reset + the match kernel on the plan's stream, bracketed by hipEvents.  With RX_KERNEL_AUTO the first
+ * launch for a batch shape (and every 32nd of the same shape) first probes — sample launches and a stream synchronisation
+ * — unless the shape was tuned (rx_plan_tune) or the plan was created with RX_OPT_NO_PROBE: then this call only enqueues. */
 int rx_plan_launch(rx_plan* plan);
+/* Run RX_KERNEL_AUTO's probes NOW for the batch the plan holds (input set, nothing else needed) and pin the decision to
+ * its shape bucket (ceil log2 of stream count and length): later launches of that shape never probe and never
+ * synchronise the stream.  Serving recipe: tune once per shape at start-up, create the plan with RX_OPT_NO_PROBE so that
+ * an untuned shape falls back to the default instead of probing.  Blocks until the probes have finished. */
+int rx_plan_tune(rx_plan* plan);
+/* Non-blocking: which of the plan's streams still have work queued — bit 0 uploads, bit 1 kernels, bit 2 downloads of
+ * rx_plan_run, bit 3 the launch stream (rx_opts.stream).  0 after rx_plan_run has returned, also with an error. */
+int rx_plan_busy(rx_plan* plan, uint32_t* busy);
 /* Wait for the last launch; kernel_ms (optional) = its hipEvent duration. */
 int rx_plan_sync(rx_plan* plan, double* kernel_ms);
 /* hipEvent durations of every launch since the previous call (or plan creation): their number,
@@ -282,13 +299,15 @@ int rx_plan_kernel_times(rx_plan* plan, uint32_t* n_launches, double* sum_ms, do
 /* Copy the last launch's results to the caller's arrays (sorted events, counts, ...). */
 int rx_plan_download(rx_plan* plan, rx_result* res);
 /* Host buffers in, host results out, in ONE call — the same results as rx_plan_upload + rx_plan_launch +
- * rx_plan_download, but pipelined: the batch is cut into up to 4 blocks of streams, each with its own HIP stream, so
- * that the upload of block i+1, the kernel of block i and the download of block i-1 overlap (PCIe is full duplex;
- * blocks of different streams share the GPU).  Host memory that is page-locked — registered with rx_host_register, or
- * allocated pinned by the caller — is read and written by DMA directly; pageable memory works too, at the speed of the
- * runtime's staging copies.  The plan must have been created for at least n_streams / stream_len; the caller's start
- * sets are not supported here (streams start from reset).  Blocks report accept events into equal shares of the plan's
- * event capacity (an overflow in any share sets events_overflow). */
+ * rx_plan_download, but pipelined: the batch is cut into up to 8 blocks of >= 32 768 streams that share three HIP
+ * streams (uploads, kernels, downloads), so that the upload of block i+1, the kernel of block i and the download of
+ * block i-1 overlap.  Host memory that is page-locked — registered with rx_host_register, or allocated pinned by the
+ * caller — is read and written by DMA directly; pageable memory works too, at the speed of the runtime's staging copies.
+ * The plan must have been created for at least n_streams / stream_len; the caller's start sets are not supported here
+ * (streams start from reset).  Capacities hold for the WHOLE call: the blocks fill the plan's event buffer (and the
+ * caller's final_states) one behind the other, so events_overflow / final_states_overflow are set only when the batch's
+ * total exceeds the capacity, wherever in the batch the matches lie.  On ANY error return no copy is in flight any more:
+ * the caller may release `bytes` and the result arrays at once. */
 int rx_plan_run(rx_plan* plan, const uint8_t* bytes, size_t n_streams, size_t stream_len, size_t stride, rx_result* res);
 void rx_plan_free(rx_plan* plan);
 

@@ -381,6 +381,17 @@ struct rx_plan {
   bool have_input = false, launched = false;
   bool auto_decided = false;   // RX_KERNEL_AUTO: the probe's decision is valid for the current batch
   uint32_t batches_since_probe = 0;
+  // AUTO's decisions by batch shape (ceil log2 of the stream count and of the stream length): a plan that is fed
+  // alternating shapes probes each of them once, not on every change.  `pinned`: made by rx_plan_tune — never probed again.
+  struct AutoChoice {
+    uint32_t kernel = RX_KERNEL_SYM_PACK, lanes = 16;
+    bool prune = false, fold = false, reg_skip = true, probe_prune = false, pinned = false;
+    double probe_active = 0;
+  };
+  std::map<uint32_t, AutoChoice> choices;
+  uint32_t shape_key = 0;
+  bool choice_pinned = false;  // the current decision came from rx_plan_tune
+  bool tuning = false;         // inside rx_plan_tune: probe even under RX_OPT_NO_PROBE
   uint32_t auto_kernel = RX_KERNEL_SYM_PACK;
   uint32_t auto_lanes = 16;    // streams per wavefront chosen for the pack kernel
   bool auto_prune = false;     // look-ahead pruning chosen (and verified at auto_lanes) by the probe
@@ -399,18 +410,29 @@ struct rx_plan {
   };
   std::vector<Pipe> pipes;
   hipStream_t s_in = nullptr, s_k = nullptr, s_out = nullptr;  // uploads / kernels / downloads of rx_plan_run
+  // rx_plan_run: one capacity for the whole call.  d_run_ctr[0] = accept events of all blocks so far (their slot counter),
+  // [1] = entries of the compact final sets so far, [2 + b] / [10 + b] = those two after block b (snapshots taken on the
+  // kernel stream, so that the host can cut the shared buffers back into blocks); h_run_ctr: page-locked copy
+  unsigned long long* d_run_ctr = nullptr;
+  unsigned long long* h_run_ctr = nullptr;
   // one hipEvent pair per launch since the last rx_plan_kernel_times() call
   std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
   size_t n_timed = 0;
   double last_ms = 0;
 };
 
+// struct_size == 0 was documented by ABI 1 as "this version": its meaning is frozen at the ABI-1 layouts (rx_opts up to
+// `flags`, rx_result up to the end of stats.tb_cycles), so that a caller built against ABI 1 that left the field at 0
+// is neither read nor written past the end of its structs.  Callers that want the newer fields state their size.
+static constexpr size_t RX_OPTS_ABI1_BYTES = offsetof(rx_opts, flags);
+static constexpr size_t RX_RESULT_ABI1_BYTES = offsetof(rx_result, stats) + offsetof(rx_stats, lanes_used);
+
 // rx_opts as the caller's version of the header laid it out: fields beyond its struct_size read as 0
 static rx_opts read_opts(const rx_opts* opts) {
   rx_opts o{};
   o.device = -1;
   if (opts) {
-    const size_t have = opts->struct_size ? std::min<size_t>(opts->struct_size, sizeof(rx_opts)) : sizeof(rx_opts);
+    const size_t have = opts->struct_size ? std::min<size_t>(opts->struct_size, sizeof(rx_opts)) : RX_OPTS_ABI1_BYTES;
     memcpy(&o, opts, have);
   }
   return o;
@@ -504,6 +526,8 @@ extern "C" void rx_plan_free(rx_plan* p) {
   (void)hipFree(p->d_spill_streams);
   (void)hipFree(p->d_spill_k);
   (void)hipFree(p->d_spill_rows);
+  (void)hipFree(p->d_run_ctr);
+  if (p->h_run_ctr) (void)hipHostFree(p->h_run_ctr);
   for (auto& e : p->evs) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto& q : p->pipes) {
     (void)hipFree(q.d_set);
@@ -519,13 +543,53 @@ extern "C" void rx_plan_free(rx_plan* p) {
   delete p;
 }
 
+static uint32_t ceil_log2(size_t v) {
+  uint32_t b = 0;
+  while (b < 63 && ((size_t)1 << b) < v) b++;
+  return b;
+}
+
+static void store_choice(rx_plan* p, bool pinned) {
+  rx_plan::AutoChoice c;
+  c.kernel = p->auto_kernel;
+  c.lanes = p->auto_lanes;
+  c.prune = p->auto_prune;
+  c.fold = p->auto_fold;
+  c.reg_skip = p->auto_reg_skip;
+  c.probe_prune = p->probe_prune;
+  c.probe_active = p->probe_active;
+  c.pinned = pinned;
+  p->choices[p->shape_key] = c;
+  p->choice_pinned = pinned;
+}
+
 static int set_batch(rx_plan* p, size_t n_streams, size_t stream_len, size_t stride) {
   if (n_streams == 0 || n_streams > p->max_streams || stream_len > p->max_len || stride < stream_len)
     return RX_EINVAL;
-  // AUTO's probe costs about as much as a launch: a plan that is fed batch after batch of the same shape (serving)
-  // keeps its decision and looks again every 32nd batch; a wrong guess only costs speed (hand-offs keep it exact)
+  // AUTO's probe costs about as much as a launch.  Its decision is kept per shape bucket; a plan that is fed batch after
+  // batch of one shape (serving) looks again every 32nd batch — unless the decision was made by rx_plan_tune or the plan
+  // was created with RX_OPT_NO_PROBE.  A wrong guess only costs speed (hand-offs keep every kernel exact).
   const bool same_shape = p->have_input && p->n_streams == n_streams && p->stream_len == stream_len;
-  if (!same_shape || ++p->batches_since_probe >= 32) {
+  if (!same_shape) {
+    p->shape_key = (ceil_log2(n_streams) << 8) | ceil_log2(stream_len + 1);
+    auto it = p->choices.find(p->shape_key);
+    p->batches_since_probe = 0;
+    if (it != p->choices.end()) {
+      const rx_plan::AutoChoice& c = it->second;
+      p->auto_kernel = c.kernel;
+      p->auto_lanes = c.lanes;
+      p->auto_prune = c.prune;
+      p->auto_fold = c.fold;
+      p->auto_reg_skip = c.reg_skip;
+      p->probe_prune = c.probe_prune;
+      p->probe_active = c.probe_active;
+      p->choice_pinned = c.pinned;
+      p->auto_decided = true;
+    } else {
+      p->auto_decided = false;
+      p->choice_pinned = false;
+    }
+  } else if (!p->choice_pinned && !(p->opts.flags & RX_OPT_NO_PROBE) && ++p->batches_since_probe >= 32) {
     p->auto_decided = false;
     p->batches_since_probe = 0;
   }
@@ -638,6 +702,7 @@ static void fill_common(rx_plan* p, RxParams& a) {
   a.state0_entry = (h.accept_bits[0] & 1u) ? RXE_ACCEPT : 0u;
   a.nw64x2 = 2u * ((h.size + 63u) / 64u);
   a.counters = p->d_counters;
+  a.ev_count = p->d_counters;
   a.pin_state = h.pin_state;
   a.pin_degree = h.pin_state != 0xFFFFFFFFu ? h.row_ptr()[h.pin_state + 1] - h.row_ptr()[h.pin_state] : 0;
 }
@@ -901,8 +966,15 @@ static int prepare_launch(rx_plan* p) {
   // few long streams from reset (the reference's own run is one lock-step pair): latency per pass is what counts, and the
   // register-resident kernel has the shortest pass; it has no statistics build
   const bool reg_ok = p->opts.collect_stats == 0 && !p->have_init && p->tab.regidx;
+  // RX_OPT_NO_PROBE: nothing below may run a kernel or wait for the stream; a shape rx_plan_tune has not seen gets the
+  // defaults (the pack kernel at 16 streams per wavefront; up to 4 streams the register kernel's skipping build)
+  const bool may_probe = p->tuning || !(p->opts.flags & RX_OPT_NO_PROBE);
   if (kernel == RX_KERNEL_AUTO && p->n_streams <= 4 && reg_ok) {
     kernel = RX_KERNEL_SYM_REG;
+    if (!p->auto_decided && !may_probe) {
+      p->auto_reg_skip = true;
+      p->auto_decided = true;
+    }
     if (!p->auto_decided) {
       // Which build: a trial run over the first 8 192 bytes with the one that steps over idle passes, which counts the
       // groups of passes it skipped in the second half (the busier shipped trace: none after pass 680 — the `.*` states
@@ -932,6 +1004,7 @@ static int prepare_launch(rx_plan* p) {
                   p->auto_reg_skip ? "step over them" : "plain build");
       }
       p->auto_decided = true;
+      store_choice(p, p->tuning);
     }
   }
   // (more streams, but at most 16 wavefronts of them per SIMD: the probe times both kernels on the batch)
@@ -939,9 +1012,17 @@ static int prepare_launch(rx_plan* p) {
   // the probe also serves an explicit RX_KERNEL_SYM_PACK: whether look-ahead pruning pays depends on the input
   const bool probe_for_pack = kernel == RX_KERNEL_SYM_PACK && p->tab.symidx_p && p->opts.collect_stats == 0;
   if ((kernel == RX_KERNEL_AUTO || probe_for_pack) && !pair && !p->have_init) {
+    if (!p->auto_decided && !may_probe) {
+      p->auto_kernel = RX_KERNEL_SYM_PACK;
+      p->auto_lanes = 16;
+      p->auto_prune = p->auto_fold = p->probe_prune = false;
+      p->auto_reg_skip = p->tab.pin_tab != nullptr;
+      p->auto_decided = true;
+    }
     if (!p->auto_decided) {
       if ((rc = auto_probe(p, reg_eligible))) return rc;
       p->auto_decided = true;
+      store_choice(p, p->tuning);
       if (p->opts.flags & RX_OPT_VERBOSE)
         fprintf(stderr, "[rxmatch] AUTO -> kernel %u, %u streams per wavefront, look-ahead pruning %s, folding %s\n",
                 p->auto_kernel, p->auto_lanes, p->auto_prune ? "on" : "off", p->auto_fold ? "on" : "off");
@@ -1024,6 +1105,7 @@ extern "C" int rx_plan_launch(rx_plan* p) {
   p->d_counters = p->d_cset[p->cur_set];
   p->d_mct = p->d_counters + 16;
   a.counters = p->d_counters;
+  a.ev_count = p->d_counters;
   a.match_count_total = p->d_mct;
   if (a.spill_count) a.spill_count = p->d_counters + 3;
   a.zero_next = p->d_cset[p->cur_set ^ 1];
@@ -1043,6 +1125,49 @@ extern "C" int rx_plan_launch(rx_plan* p) {
   HIPCHK(hipEventRecord(ev.second, p->stream));
   p->n_timed++;
   p->launched = true;
+  return RX_OK;
+  RX_CATCH
+}
+
+extern "C" int rx_plan_tune(rx_plan* p) {
+  RX_TRY
+  if (!p) return RX_EINVAL;
+  if (!p->have_input) return RX_ESTATE;
+  int dev;
+  int rc = bind_device(p->device, &dev);
+  if (rc) return rc;
+  // AUTO's probes for the batch the plan holds, now: sample runs, timed candidates, stream synchronisation — everything
+  // rx_plan_launch would otherwise do on the first batch of a shape and again on every 32nd.  The decision is pinned to
+  // the shape bucket: later launches of that shape (also after other shapes in between) enqueue and return.
+  p->auto_decided = false;
+  p->choices.erase(p->shape_key);
+  p->tuning = true;
+  rc = prepare_launch(p);
+  p->tuning = false;
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(p->stream));
+  if (p->opts.kernel != RX_KERNEL_AUTO && !p->choices.count(p->shape_key)) store_choice(p, true);  // (nothing to decide: pin the no-op)
+  auto it = p->choices.find(p->shape_key);
+  if (it != p->choices.end()) it->second.pinned = true;
+  p->choice_pinned = true;
+  return RX_OK;
+  RX_CATCH
+}
+
+extern "C" int rx_plan_busy(rx_plan* p, uint32_t* busy) {
+  RX_TRY
+  if (!p || !busy) return RX_EINVAL;
+  int dev;
+  int rc = bind_device(p->device, &dev);
+  if (rc) return rc;
+  *busy = 0;
+  const hipStream_t ss[4] = {p->s_in, p->s_k, p->s_out, p->stream};
+  for (int i = 0; i < 4; i++) {
+    if (i < 3 && !ss[i]) continue;  // (rx_plan_run's streams exist from its first call on; the launch stream may be the null stream)
+    const hipError_t e = hipStreamQuery(ss[i]);
+    if (e == hipErrorNotReady) { *busy |= 1u << i; (void)hipGetLastError(); }
+    else if (e != hipSuccess) return hip_fail(e, "hipStreamQuery");
+  }
   return RX_OK;
   RX_CATCH
 }
@@ -1094,20 +1219,20 @@ static bool ev_less(const rx_event& a, const rx_event& b) {
 // arrival order — per stream already ascending in k (a wavefront's passes allocate their slots one after the other) —
 // so a stable counting sort by stream does nearly everything in O(n); an insertion sort per stream finishes equal-k
 // runs and anything an unusual kernel left out of order.  (std::sort on 75 000 events took 5 ms of a 8 ms call.)
-static void sort_events(std::vector<rx_event>& ev, uint32_t lo, size_t n_streams, std::vector<rx_event>& scratch) {
-  const size_t n = ev.size();
+static void sort_events(rx_event* ev, size_t n, uint32_t lo, size_t n_streams, std::vector<rx_event>& scratch) {
   if (n < 2) return;
-  if (n < 64 || n_streams > 8 * n + 1024) { std::sort(ev.begin(), ev.end(), ev_less); return; }
+  if (n < 64 || n_streams > 8 * n + 1024) { std::sort(ev, ev + n, ev_less); return; }
   std::vector<uint32_t> at(n_streams + 1, 0u);
-  for (const rx_event& e : ev) {
-    if (e.stream < lo || e.stream - lo >= n_streams) { std::sort(ev.begin(), ev.end(), ev_less); return; }  // not ours: be safe
+  for (size_t i = 0; i < n; i++) {
+    const rx_event& e = ev[i];
+    if (e.stream < lo || e.stream - lo >= n_streams) { std::sort(ev, ev + n, ev_less); return; }  // not ours: be safe
     at[e.stream - lo + 1]++;
   }
   for (size_t i = 0; i < n_streams; i++) at[i + 1] += at[i];
   scratch.resize(n);
   {
     std::vector<uint32_t> pos(at.begin(), at.end() - 1);
-    for (const rx_event& e : ev) scratch[pos[e.stream - lo]++] = e;
+    for (size_t i = 0; i < n; i++) scratch[pos[ev[i].stream - lo]++] = ev[i];
   }
   for (size_t st = 0; st < n_streams; st++) {
     const uint32_t b = at[st], e = at[st + 1];
@@ -1118,12 +1243,12 @@ static void sort_events(std::vector<rx_event>& ev, uint32_t lo, size_t n_streams
       scratch[j] = x;
     }
   }
-  ev.swap(scratch);
+  memcpy(ev, scratch.data(), n * sizeof(rx_event));
 }
 
 // rx_result as the caller's version of the header laid it out (see read_opts)
 static size_t result_bytes(const rx_result* res) {
-  return res->struct_size ? std::min<size_t>(res->struct_size, sizeof(rx_result)) : sizeof(rx_result);
+  return res->struct_size ? std::min<size_t>(res->struct_size, sizeof(rx_result)) : RX_RESULT_ABI1_BYTES;
 }
 
 static int plan_download(rx_plan* p, rx_result* res);
@@ -1160,6 +1285,9 @@ static int plan_download(rx_plan* p, rx_result* res) {
     for (int q = 0; q < 7 && tot; q++)
       fprintf(stderr, "[rxmatch] pack pass phase %d %-44s %5.1f %%  (%.0f cycles per wave-pass)\n", q, names[q],
               100.0 * cnt[8 + q] / tot, (double)cnt[8 + q] / ((double)((p->n_streams + 15) / 16) * p->params.n_passes));
+    if (cnt[15] & 0xFFFFFFFFull)
+      fprintf(stderr, "[rxmatch] pack kernel (stamped build), wave 0: %llu shader cycles in %.3f ms = %.0f MHz under load\n", (cnt[15] >> 32) << 6,
+              (double)(cnt[15] & 0xFFFFFFFFull) * 1e-5, (double)((cnt[15] >> 32) << 6) / (double)(cnt[15] & 0xFFFFFFFFull) * 100.0);
   }
   if ((p->opts.flags & RX_OPT_VERBOSE) && p->cfg.kernel == RX_KERNEL_SYM_REG && cnt[9])
     fprintf(stderr, "[rxmatch] register kernel, stream 0: %llu shader cycles in %.3f ms = %.0f MHz, %.0f cycles per pass\n", cnt[8],
@@ -1192,7 +1320,7 @@ static int plan_download(rx_plan* p, rx_result* res) {
   if (res->events && res->events_cap && captured) {
     std::vector<rx_event> tmp(captured), scratch;
     HIPCHK(hipMemcpy(tmp.data(), p->d_events, captured * sizeof(rx_event), hipMemcpyDeviceToHost));
-    sort_events(tmp, p->params.stream_base, p->n_streams, scratch);  // device order is arrival order; canonical = (stream,k,state)
+    sort_events(tmp.data(), tmp.size(), p->params.stream_base, p->n_streams, scratch);  // device order is arrival order; canonical = (stream,k,state)
     const size_t n = std::min(captured, res->events_cap);
     memcpy(res->events, tmp.data(), n * sizeof(rx_event));
     res->n_events = n;
@@ -1254,20 +1382,58 @@ extern "C" int rx_plan_run(rx_plan* p, const uint8_t* bytes, size_t n_streams, s
   RX_CATCH
 }
 
+static int plan_run_body(rx_plan* p, const uint8_t* bytes, size_t n_streams, size_t stream_len, size_t stride, rx_result* res,
+                         bool* enqueued);
+
+// Error discipline of the pipelined call: everything that can be checked without the device is checked before the first
+// enqueue; once copies are in flight from / into the caller's arrays, EVERY exit that reports a failure first waits for the
+// three streams — the caller is free to release its buffers as soon as it sees the error code.
 static int plan_run(rx_plan* p, const uint8_t* bytes, size_t n_streams, size_t stream_len, size_t stride, rx_result* res) {
+  bool enqueued = false;
+  const int rc = plan_run_body(p, bytes, n_streams, stream_len, stride, res, &enqueued);
+  if (rc != RX_OK && enqueued) {
+    const std::string keep = g_last_hip;  // (the drain must not replace the text of the failure that is being reported)
+    if (p->s_in) (void)hipStreamSynchronize(p->s_in);
+    if (p->s_k) (void)hipStreamSynchronize(p->s_k);
+    if (p->s_out) (void)hipStreamSynchronize(p->s_out);
+    (void)hipStreamSynchronize(p->stream);
+    (void)hipGetLastError();
+    g_last_hip = keep;
+    p->launched = false;
+    p->sets_clean = false;
+  }
+  return rc;
+}
+
+static int plan_run_body(rx_plan* p, const uint8_t* bytes, size_t n_streams, size_t stream_len, size_t stride, rx_result* res,
+                         bool* enqueued) {
   int dev;
   int rc = bind_device(p->device, &dev);
   if (rc) return rc;
-  if ((rc = set_batch(p, n_streams, stream_len, stride))) return rc;
   const RxHostNfa& h = p->nfa->h;
   const uint32_t size = h.size;
   const size_t nw64 = ((size_t)size + 63) / 64, set_words = 16 + (size_t)size;
+  // ---- checks that need no device state (nothing has been enqueued yet) ----
+  if (n_streams == 0 || n_streams > p->max_streams || stream_len > p->max_len || stride < stream_len) return RX_EINVAL;
   if ((res->match_count && !p->want_mc) || (res->anymatch && !p->want_am) || (res->final_active && !p->want_final)) return RX_ESTATE;
   const bool compact = res->final_states || res->final_off || res->final_cnt;
   if (compact) {
     if (!res->final_states || !res->final_off || !res->final_cnt || res->final_states_cap == 0) return RX_EINVAL;
     if (!p->want_final) return RX_ESTATE;
     if (res->final_states_cap > 0xFFFFFFFFull) return RX_EINVAL;
+  }
+  {
+    const uint64_t passes = passes_for(stream_len, p->opts.mode);
+    if (p->opts.k_base + passes > (1ull << 32)) return RX_EINVAL;
+    if (res->anymatch && res->anymatch_stride < (size_t)((passes + 31) / 32)) return RX_EINVAL;
+    if (p->opts.collect_stats == 2 &&
+        ((n_streams & 1) || (p->opts.kernel != RX_KERNEL_AUTO && p->opts.kernel != RX_KERNEL_SYM_PACK)))
+      return RX_EINVAL;
+  }
+  // a preceding rx_plan_launch may still be reading the plan's input and output buffers on the plan's own stream
+  HIPCHK(hipStreamSynchronize(p->stream));
+  if ((rc = set_batch(p, n_streams, stream_len, stride))) return rc;
+  if (compact) {
     if (res->final_states_cap > p->fstates_cap) {
       (void)hipFree(p->d_fstates);
       p->d_fstates = nullptr;
@@ -1292,11 +1458,12 @@ static int plan_run(rx_plan* p, const uint8_t* bytes, size_t n_streams, size_t s
   }
   p->d_in = p->d_in_own;
   p->stride = pitch;
-  // blocks of streams: 32 768 or more each (smaller launches leave SIMDs idle), at most eight, sizes a multiple of
-  // 1 024 (lock-step pairs stay together).  Three HIP streams: uploads, kernels, downloads — a copy runs beside a
-  // kernel, the two copy directions share the link (measured on the MI355X box: 56 GB/s in either direction or in
-  // both together), so the pipeline's floor is (input + output bytes) / 56 GB/s.
-  size_t n_blocks = std::min<size_t>(8, std::max<size_t>(1, n_streams / 32768));
+  // blocks of streams: 32 768 or more each (smaller launches leave SIMDs idle), at most EIGHT, sizes a multiple of
+  // 1 024 (lock-step pairs stay together).  THREE HIP streams shared by all blocks: uploads, kernels, downloads — a copy
+  // runs beside a kernel, the two copy directions share the link (measured on the MI355X box: 56 GB/s in either direction
+  // or in both together), so the pipeline's floor is (input + output bytes) / 56 GB/s.
+  constexpr size_t MAX_BLOCKS = 8;
+  size_t n_blocks = std::min<size_t>(MAX_BLOCKS, std::max<size_t>(1, n_streams / 32768));
   size_t per = (n_streams + n_blocks - 1) / n_blocks;
   per = (per + 1023) & ~(size_t)1023;
   n_blocks = (n_streams + per - 1) / per;
@@ -1304,6 +1471,10 @@ static int plan_run(rx_plan* p, const uint8_t* bytes, size_t n_streams, size_t s
     HIPCHK(hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&p->s_k, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking));
+  }
+  if (!p->d_run_ctr) {
+    HIPCHK(hipMalloc((void**)&p->d_run_ctr, (2 + 2 * MAX_BLOCKS) * sizeof(unsigned long long)));
+    HIPCHK(hipHostMalloc((void**)&p->h_run_ctr, (2 + 2 * MAX_BLOCKS) * sizeof(unsigned long long), hipHostMallocDefault));
   }
   while (p->pipes.size() < n_blocks) {
     rx_plan::Pipe q;
@@ -1316,6 +1487,7 @@ static int plan_run(rx_plan* p, const uint8_t* bytes, size_t n_streams, size_t s
   }
   auto upload = [&](size_t b) -> int {
     const size_t s0 = b * per, cnt = std::min(per, n_streams - s0);
+    *enqueued = true;
     if (stream_len) {
       if (stride == pitch && stream_len == pitch)
         HIPCHK(hipMemcpyAsync(p->d_in_own + s0 * pitch, bytes + s0 * stride, cnt * pitch, hipMemcpyHostToDevice, p->s_in));
@@ -1330,17 +1502,17 @@ static int plan_run(rx_plan* p, const uint8_t* bytes, size_t n_streams, size_t s
   if ((rc = upload(0))) return rc;
   if (!p->auto_decided) HIPCHK(hipStreamSynchronize(p->s_in));
   if ((rc = prepare_launch(p))) return rc;
-  if (p->opts.collect_stats == 2 && (per & 1)) return RX_EINVAL;
   HIPCHK(hipStreamSynchronize(p->stream));  // (the probe ran on the plan's own stream)
-  const size_t ev_share = p->events_cap / n_blocks;
-  const size_t fs_share = compact ? res->final_states_cap / n_blocks : 0;
-  if (compact && fs_share == 0) return RX_EINVAL;
   const size_t am_need = (size_t)((p->params.n_passes + 31) / 32);
-  if (res->anymatch && res->anymatch_stride < am_need) return RX_EINVAL;
   const bool two_tier = p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK ||
                         p->cfg.kernel == RX_KERNEL_DFA || p->cfg.kernel == RX_KERNEL_SYM_REG;
   for (size_t b = 1; b < n_blocks; b++)  // all uploads are queued before any download (both use the same link)
     if ((rc = upload(b))) return rc;
+  // ONE capacity for the whole call: the blocks' kernels run one after the other on the kernel stream and take their
+  // event slots from one counter over the plan's whole event buffer (and the compaction kernels theirs from one counter
+  // over the caller-sized list buffer); a snapshot of both counters behind every block tells the host where the block's
+  // part ends.  A call whose events all lie in one block loses none as long as the total fits.
+  HIPCHK(hipMemsetAsync(p->d_run_ctr, 0, (2 + 2 * MAX_BLOCKS) * sizeof(unsigned long long), p->s_k));
   for (size_t b = 0; b < n_blocks; b++) {
     rx_plan::Pipe& q = p->pipes[b];
     const size_t s0 = b * per, cnt = std::min(per, n_streams - s0);
@@ -1349,8 +1521,9 @@ static int plan_run(rx_plan* p, const uint8_t* bytes, size_t n_streams, size_t s
     a.bytes = p->d_in_own + s0 * pitch;
     a.n_streams = (uint32_t)cnt;
     a.stream_base = (uint32_t)s0;
-    a.events = ev_share ? p->d_events + b * ev_share : nullptr;
-    a.events_cap = (uint32_t)ev_share;
+    a.events = p->events_cap ? p->d_events : nullptr;
+    a.events_cap = (uint32_t)p->events_cap;
+    a.ev_count = p->d_run_ctr;
     a.counters = q.d_set;
     a.match_count_total = q.d_set + 16;
     a.zero_next = nullptr;
@@ -1373,11 +1546,13 @@ static int plan_run(rx_plan* p, const uint8_t* bytes, size_t n_streams, size_t s
     HIPCHK(hipEventRecord(q.k0, p->s_k));
     hipError_t e = (hipError_t)rx_launch(a, cfg, p->s_k);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
-    if (compact) {  // the block's share of the caller's capacity; counter = a word of the block's set nothing else uses
-      e = (hipError_t)rx_launch_final_compact(a.final_active, a.n_streams, a.nw64x2, p->d_fstates + b * fs_share, (uint32_t)fs_share,
-                                              p->d_foff + s0, p->d_fcnt + s0, q.d_set + 15, p->s_k);
+    if (compact) {  // the lists of all blocks share the caller's capacity; offsets are positions in the whole buffer
+      e = (hipError_t)rx_launch_final_compact(a.final_active, a.n_streams, a.nw64x2, p->d_fstates, (uint32_t)res->final_states_cap,
+                                              p->d_foff + s0, p->d_fcnt + s0, p->d_run_ctr + 1, p->s_k);
       if (e != hipSuccess) return hip_fail(e, "final-set compaction launch");
     }
+    HIPCHK(hipMemcpyAsync(p->d_run_ctr + 2 + b, p->d_run_ctr, sizeof(unsigned long long), hipMemcpyDeviceToDevice, p->s_k));
+    HIPCHK(hipMemcpyAsync(p->d_run_ctr + 2 + MAX_BLOCKS + b, p->d_run_ctr + 1, sizeof(unsigned long long), hipMemcpyDeviceToDevice, p->s_k));
     HIPCHK(hipEventRecord(q.k1, p->s_k));
     // results of the block straight into the caller's arrays
     HIPCHK(hipStreamWaitEvent(p->s_out, q.k1, 0));
@@ -1400,9 +1575,14 @@ static int plan_run(rx_plan* p, const uint8_t* bytes, size_t n_streams, size_t s
     if (res->match_count)
       HIPCHK(hipMemcpyAsync(res->match_count + s0 * size, p->d_mc + s0 * size, cnt * size * sizeof(uint32_t), hipMemcpyDeviceToHost,
                             p->s_out));
-    // events of the block: the count is only known on the device, so its whole share comes over — unless that is
-    // large, in which case they are fetched after the block has finished (below)
+    // (test hook, RX_OPT_INJECT_RUN_FAULT: fail here, with block 0's kernels and copies in flight)
+    if (b == 0 && (p->opts.flags & RX_OPT_INJECT_RUN_FAULT)) {
+      g_last_hip = "injected fault (RX_OPT_INJECT_RUN_FAULT)";
+      return RX_EHIP;
+    }
   }
+  // the counters and their per-block snapshots (the last block's k1 orders this copy behind every kernel)
+  HIPCHK(hipMemcpyAsync(p->h_run_ctr, p->d_run_ctr, (2 + 2 * MAX_BLOCKS) * sizeof(unsigned long long), hipMemcpyDeviceToHost, p->s_out));
   const bool verbose = (p->opts.flags & RX_OPT_VERBOSE) != 0;
   const auto w_issued = std::chrono::steady_clock::now();
   HIPCHK(hipStreamSynchronize(p->s_out));
@@ -1421,7 +1601,6 @@ static int plan_run(rx_plan* p, const uint8_t* bytes, size_t n_streams, size_t s
   res->n_events = 0;
   res->events_overflow = 0;
   if (res->match_count_total) memset(res->match_count_total, 0, (size_t)size * sizeof(uint64_t));
-  std::vector<rx_event> tmp, scratch;
   unsigned long long spilled = 0, pair_cost = 0;
   for (size_t b = 0; b < n_blocks; b++) {
     rx_plan::Pipe& q = p->pipes[b];
@@ -1430,42 +1609,40 @@ static int plan_run(rx_plan* p, const uint8_t* bytes, size_t n_streams, size_t s
     st.kernel_ms += ms;
     st.n_launches += two_tier ? 2 : 1;
     const unsigned long long* cnt = q.h_set;
-    st.n_events += cnt[0];
     st.sum_active += cnt[1];
     st.sum_edges += cnt[2];
     spilled += cnt[3];
     pair_cost += cnt[4];
     if (res->match_count_total)
       for (uint32_t i = 0; i < size; i++) res->match_count_total[i] += cnt[16 + i];
-    const size_t captured = (size_t)std::min<unsigned long long>(cnt[0], ev_share);
-    if (cnt[0] > ev_share && res->events) res->events_overflow = 1u;
-    if (res->events && res->events_cap && captured) {
-      tmp.resize(captured);
-      HIPCHK(hipMemcpy(tmp.data(), p->d_events + b * ev_share, captured * sizeof(rx_event), hipMemcpyDeviceToHost));
-      sort_events(tmp, (uint32_t)(b * per), std::min(per, n_streams - b * per), scratch);
-      const size_t room = res->events_cap - res->n_events, n = std::min(captured, room);
-      memcpy(res->events + res->n_events, tmp.data(), n * sizeof(rx_event));
-      res->n_events += n;
-      if (n < captured) res->events_overflow = 1u;
+  }
+  const unsigned long long* ev_after = p->h_run_ctr + 2;  // accept events of blocks 0..b
+  const unsigned long long ev_total = p->h_run_ctr[0];
+  st.n_events = ev_total;
+  if (ev_total > p->events_cap && res->events) res->events_overflow = 1u;
+  const size_t captured = (size_t)std::min<unsigned long long>(ev_total, p->events_cap);
+  if (res->events && res->events_cap && captured) {
+    // the device buffer holds the blocks' events back to back in launch order (the first `captured` slots); each block's
+    // part is brought into (stream, k, state) order on its own
+    std::vector<rx_event> tmp(captured), scratch;
+    HIPCHK(hipMemcpy(tmp.data(), p->d_events, captured * sizeof(rx_event), hipMemcpyDeviceToHost));
+    for (size_t b = 0; b < n_blocks; b++) {
+      const size_t lo = (size_t)std::min<unsigned long long>(b ? ev_after[b - 1] : 0ull, captured);
+      const size_t hi = (size_t)std::min<unsigned long long>(ev_after[b], captured);
+      if (hi > lo) sort_events(tmp.data() + lo, hi - lo, (uint32_t)(b * per), std::min(per, n_streams - b * per), scratch);
     }
+    const size_t n = std::min(captured, res->events_cap);
+    memcpy(res->events, tmp.data(), n * sizeof(rx_event));
+    res->n_events = n;
+    if (n < captured) res->events_overflow = 1u;
   }
   if (compact) {
-    // the blocks' lists, packed one behind the other in the caller's array; offsets become positions in that array
-    res->n_final_states = 0;
-    res->final_states_overflow = 0;
-    for (size_t b = 0; b < n_blocks; b++) {
-      const size_t s0 = b * per, cnt_s = std::min(per, n_streams - s0);
-      const unsigned long long needed = p->pipes[b].h_set[15];
-      const size_t have_n = (size_t)std::min<unsigned long long>(needed, fs_share);
-      if (needed > fs_share) res->final_states_overflow = 1u;
-      if (have_n)
-        HIPCHK(hipMemcpy(res->final_states + res->n_final_states, p->d_fstates + b * fs_share, have_n * sizeof(uint32_t),
-                         hipMemcpyDeviceToHost));
-      const uint32_t shift = (uint32_t)res->n_final_states;
-      if (shift)
-        for (size_t s = s0; s < s0 + cnt_s; s++) res->final_off[s] += shift;
-      res->n_final_states += have_n;
-    }
+    // (final_off is a position in final_states; a set that did not fit wholly is cut at the capacity, final_cnt stays exact)
+    const unsigned long long needed = p->h_run_ctr[1];
+    const size_t have_n = (size_t)std::min<unsigned long long>(needed, res->final_states_cap);
+    res->final_states_overflow = needed > res->final_states_cap ? 1u : 0u;
+    if (have_n) HIPCHK(hipMemcpy(res->final_states, p->d_fstates, have_n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    res->n_final_states = have_n;
   }
   if (p->cfg.stats) {
     st.alg_bytes = (uint64_t)p->params.n_consume * n_streams + 8 * st.sum_active + 4 * st.sum_edges +
@@ -1567,6 +1744,7 @@ extern "C" int rx_match_sharded(const rx_nfa* nfa, const uint8_t* bytes, size_t 
       o.device = devices ? devices[d] : d;
       o.stream = nullptr;  // a stream handle belongs to one device
       x.r = rx_result{};
+      x.r.struct_size = sizeof(rx_result);
       if (res->events && res->events_cap) {
         x.ev.resize(res->events_cap);
         x.r.events = x.ev.data();

@@ -93,6 +93,9 @@ struct RxParams {
   // outputs
   rx_event* events;
   uint32_t events_cap;
+  // where accept events take their slots in `events` (capacity events_cap): &counters[0] for a plain launch; ONE word shared
+  // by every block of an rx_plan_run call, so that the blocks fill one caller-sized buffer in launch order
+  unsigned long long* ev_count;
   unsigned long long* counters; // [0] n_events [1] sum_active [2] sum_edges [3] spilled streams [4] pair clock cost
                                 // pack statistics build: [5] entries on multi-target rows [6] of their targets, dead at once [7] its own active
   // The plan keeps TWO sets of {counters[16], match_count_total[size]} and alternates between them: the kernel of launch

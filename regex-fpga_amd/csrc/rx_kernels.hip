@@ -116,7 +116,7 @@ __device__ __forceinline__ void emit_events(const RxParams& p, bool acc, uint32_
   if (ma == 0) return;
   const uint32_t cnt = (uint32_t)__popcll(ma);
   unsigned long long base = 0;
-  if (lane == 0) base = atomicAdd(&p.counters[0], (unsigned long long)cnt);
+  if (lane == 0) base = atomicAdd(p.ev_count, (unsigned long long)cnt);
   const uint32_t blo = bcast((uint32_t)base, 0), bhi = bcast((uint32_t)(base >> 32), 0);
   base = ((unsigned long long)bhi << 32) | blo;
   if (acc) {
@@ -825,6 +825,8 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
   constexpr bool LOOK = PRUNE || FOLD;  // the window carries one byte of look-ahead
   constexpr uint32_t MARK = 1u << 29;  // STATS only: entry was inserted from a multi-target row
   unsigned long long t_prev = 0, t_sum[7] = {0, 0, 0, 0, 0, 0, 0};
+  // PROF: shader clock this wave ran at = (s_memtime delta) / (s_memrealtime delta) x 100 MHz (MI355X_MICROARCH.md, DVFS item 6)
+  const unsigned long long t0c = PROF ? __builtin_amdgcn_s_memtime() : 0ull, t0r = PROF ? __builtin_amdgcn_s_memrealtime() : 0ull;
   auto stamp = [&](int phase) {
     if (PROF) {
       unsigned long long t;
@@ -1301,8 +1303,11 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
     if (p.anymatch && (k & 31u) == 0u) store_anymatch((k >> 5) - 1u);
   }
   if (!spilled && p.anymatch && (k & 31u) != 0u) store_anymatch(k >> 5);
-  if (PROF && lane == 0)
+  if (PROF && lane == 0) {
     for (int q = 0; q < 7; q++) atomicAdd(&p.counters[8 + q], t_sum[q]);
+    // wave 0 only: [63:32] shader cycles / 64, [31:0] 100 MHz ticks, both over the whole wave
+    if (wave == 0) p.counters[15] = (((__builtin_amdgcn_s_memtime() - t0c) >> 6) << 32) | ((__builtin_amdgcn_s_memrealtime() - t0r) & 0xFFFFFFFFull);
+  }
   if ((FOLD || PRUNE) && lane == 0 && fold_entries) atomicAdd(&p.counters[7], fold_entries);
   // final active sets: the rows were zeroed at the start of this kernel; set the listed bits
   if (p.final_active && !spilled) {

@@ -18,6 +18,7 @@ KERNEL_NAMES = {0: "auto", 1: "csr_wave", 2: "sym_wave", 3: "sym_group", 4: "sym
 
 # rx_opts.flags (A/B and diagnostic switches; read at plan creation, never from the environment)
 OPT_NO_PRUNE, OPT_FORCE_PRUNE, OPT_VERBOSE, OPT_PROFILE_PACK, OPT_NO_FOLD, OPT_FORCE_FOLD, OPT_REG_NO_SKIP = 1, 2, 4, 8, 16, 32, 64
+OPT_INJECT_RUN_FAULT, OPT_NO_PROBE = 128, 256
 
 EVENT_DT = np.dtype([("stream", "<u4"), ("k", "<u4"), ("state", "<u4")])
 
@@ -67,7 +68,8 @@ ABI_SYMBOLS = ["rx_nfa_dfa_info", "rx_nfa_dfa_reset", "rx_compile_patterns", "rx
                "rx_nfa_get_info", "rx_nfa_words", "rx_nfa_free", "rx_trace_load_mem", "rx_free", "rx_match",
                "rx_match_sharded", "rx_plan_create", "rx_plan_upload", "rx_plan_set_device_input",
                "rx_plan_set_init_active", "rx_plan_launch", "rx_plan_sync", "rx_plan_kernel_times", "rx_plan_download", "rx_plan_free",
-               "rx_device_count", "rx_device_name", "rx_plan_run", "rx_host_register", "rx_host_unregister"]
+               "rx_device_count", "rx_device_name", "rx_plan_run", "rx_host_register", "rx_host_unregister", "rx_plan_tune",
+               "rx_plan_busy"]
 
 _lib = None
 
@@ -135,6 +137,8 @@ def lib():
     L.rx_plan_set_device_input.argtypes = [vp, vp, sz, sz, sz]
     L.rx_plan_set_init_active.argtypes = [vp, vp]
     L.rx_plan_launch.argtypes = [vp]
+    L.rx_plan_tune.argtypes = [vp]
+    L.rx_plan_busy.argtypes = [vp, C.POINTER(u32)]
     L.rx_plan_sync.argtypes = [vp, C.POINTER(C.c_double)]
     L.rx_plan_kernel_times.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                        C.POINTER(C.c_double)]
@@ -420,6 +424,16 @@ class Plan:
 
     def launch(self):
         _chk(lib().rx_plan_launch(self._h), "rx_plan_launch")
+
+    def tune(self):
+        """rx_plan_tune(): AUTO's probes now, decision pinned to the batch's shape (later launches only enqueue)."""
+        _chk(lib().rx_plan_tune(self._h), "rx_plan_tune")
+
+    def busy(self):
+        """rx_plan_busy(): bit mask of the plan's streams that still have work queued (non-blocking)."""
+        b = C.c_uint32()
+        _chk(lib().rx_plan_busy(self._h, C.byref(b)), "rx_plan_busy")
+        return b.value
 
     def sync(self):
         ms = C.c_double()

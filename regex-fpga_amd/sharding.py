@@ -32,7 +32,18 @@ def reduce_report(dist, device, seconds, n_events, n_bytes):
     import torch
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     c = torch.tensor([n_events, n_bytes], dtype=torch.int64, device=device)
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
     return float(t.item()), int(c[0].item()), int(c[1].item())
+
+
+def gather_per_rank(dist, device, value):
+    """One float per rank, in rank order, on every rank (all_gather of a scalar): the per-GPU kernel times of the report."""
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    if dist is None or not dist.is_initialized():
+        return [float(value)]
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]

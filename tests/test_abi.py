@@ -22,7 +22,7 @@ def test_header_symbols_exported(rx):
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/rxmatch.h but not exported"
     assert sorted(rx.host.ABI_SYMBOLS) == names  # the Python binding covers every entry point
-    assert L.rx_abi_version() == 2
+    assert L.rx_abi_version() == 3
 
 
 def test_header_is_plain_c(tmp_path):

@@ -149,6 +149,37 @@ def test_bench_starts_its_own_ranks_on_the_gpu(rx):
     _bench_self_launch(rx)
 
 
+@pytest.mark.gpu
+def test_rccl_report_path_with_one_rank():
+    """The collective calls of bench.py's N>1 path on RCCL itself (backend "nccl"), as a world of one rank on the box's GPU:
+    init with device_id, barrier, the report's all-reduces and all_gather, destroy."""
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nccl_one_rank.py")], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "nccl ok 1.5 3 4 [0.75]" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_config3_point_at_one_gpu():
+    """`bench.py --gpus 1 --config 3`: the N = 1 point of the configs[3] sweep (131 072 x 1 KB per GPU) exists and its line
+    carries the per-rank figures a sweep's efficiency is read from."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "3", "--steps", "5", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-second-distribution"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["config"]["baseline_config_index"] == 3 and d["config"]["streams_per_gpu"] == 131072 and d["n_gpus"] == 1
+    assert len(d["per_rank_kernel_ms"]) == 1 and d["per_gpu_gbit_s"][0] > 100 and d["value"] > 100
+
+
 def test_workload_generators_are_shardable(rx, traces):
     wl = rx.workloads
     lo, hi = traces[("snort_16", "lo")], traces[("snort_16", "hi")]
