@@ -423,6 +423,29 @@ def main():
             bp.close()
             del d_s
         out["small_batches_T"] = small
+        # Hand-off mix: what streams cost whose active set outgrows the pack kernel's wave-wide list.  One
+        # stream in 64 enters a 220-state trap grafted onto the shipped table (workloads.table_with_trap; no input makes a
+        # snort_16 stream do that on its own) and is finished by the wave kernel; since round 3 ONLY that stream leaves its
+        # wavefront (before: all 13 streams of the wavefront).  Same table, same batch without the trapped streams beside it.
+        tw, tsize = wl.table_with_trap(nfa.words, nfa.size)
+        tnfa = rx.Nfa.from_words(tw, tsize)
+        mix = {}
+        for name, mrows in (("clean", rows), ("one_in_64_trapped", wl.handoff_mix(traces[0], traces[1], ns, sl, first=first))):
+            d_m = torch.from_numpy(mrows).to(dev)
+            mp = rx.Plan(tnfa, ns, sl, want_match_count=False, want_anymatch=True, want_final=True, **common)
+            mp.set_device_input(d_m.data_ptr(), ns, sl, sl, keepalive=d_m)
+            time_kernel(mp, 2)
+            mavg, _, _ = time_kernel(mp, 5)
+            mres = mp.download()
+            mix[name] = {"kernel_ms_avg": round(mavg, 4), "gbit_s": round(8.0 * ns * sl / (mavg * 1e-3) / 1e9, 2),
+                         "kernel_variant": mres["stats"].get("variant", ""), "accept_events": mres["stats"]["n_events"]}
+            mp.close()
+            del d_m
+        mix["slowdown"] = round(mix["one_in_64_trapped"]["kernel_ms_avg"] / mix["clean"]["kernel_ms_avg"], 3)
+        mix["note"] = ("snort_16 table + 222-state trap; the trapped streams (1.6 %) hold 222 states per pass and run on the "
+                       "wavefront-per-stream kernel behind the pack kernel; times are both launches together")
+        out["handoff_mix_T"] = mix
+        tnfa.close()
 
     if a.all_kernels:
         extra = {}

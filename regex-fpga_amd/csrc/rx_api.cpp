@@ -1544,9 +1544,19 @@ static int plan_run_body(rx_plan* p, const uint8_t* bytes, size_t n_streams, siz
     if (p->want_mc) HIPCHK(hipMemsetAsync(p->d_mc + s0 * size, 0, cnt * size * sizeof(uint32_t), p->s_k));
     HIPCHK(hipStreamWaitEvent(p->s_k, q.up, 0));
     HIPCHK(hipEventRecord(q.k0, p->s_k));
+    // compact final sets: the pack kernel (and the wave kernel behind it) writes the lists itself and builds no rows; the
+    // other kernels leave rows, which a small kernel behind them turns into lists
+    const bool direct = compact && cfg.kernel == RX_KERNEL_SYM_PACK;
+    if (direct) {
+      a.fin_states = p->d_fstates;
+      a.fin_cap = (uint32_t)res->final_states_cap;
+      a.fin_off = p->d_foff + s0;
+      a.fin_cnt = p->d_fcnt + s0;
+      a.fin_count = p->d_run_ctr + 1;
+    }
     hipError_t e = (hipError_t)rx_launch(a, cfg, p->s_k);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
-    if (compact) {  // the lists of all blocks share the caller's capacity; offsets are positions in the whole buffer
+    if (compact && !direct) {  // the lists of all blocks share the caller's capacity; offsets are positions in the whole buffer
       e = (hipError_t)rx_launch_final_compact(a.final_active, a.n_streams, a.nw64x2, p->d_fstates, (uint32_t)res->final_states_cap,
                                               p->d_foff + s0, p->d_fcnt + s0, p->d_run_ctr + 1, p->s_k);
       if (e != hipSuccess) return hip_fail(e, "final-set compaction launch");

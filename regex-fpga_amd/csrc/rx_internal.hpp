@@ -108,6 +108,14 @@ struct RxParams {
   uint32_t* anymatch;           // [n_streams][anymatch_stride] or null
   uint32_t anymatch_stride;
   uint32_t* final_active;       // [n_streams][nw64x2] or null
+  // The final sets as compact lists, written by the match kernel itself (pack kernel and the wave kernel that finishes its
+  // hand-offs; rx_plan_run on request): states of stream s ascending at fin_states[fin_off[s] .. + fin_cnt[s]), space taken
+  // from *fin_count (one atomic per wavefront), entries at or beyond fin_cap not written.  When set, no rows are written.
+  uint32_t* fin_states;
+  uint32_t* fin_off;
+  uint32_t* fin_cnt;
+  unsigned long long* fin_count;
+  uint32_t fin_cap;
   // LDS carve
   uint32_t lds_words_per_stream;
   // spill hand-off: group kernel -> wave kernel (streams whose active set outgrew the group's list)

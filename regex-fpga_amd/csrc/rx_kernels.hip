@@ -202,9 +202,44 @@ __device__ __forceinline__ void stream_swap(const RxParams& p, StreamState& st, 
   wave_sync();
 }
 
+// The final set of one stream as a compact list (RxParams::fin_states): `src` = its bitmask (LDS, nw32 words), one
+// wavefront.  One atomic for the space, then the states in ascending order (word order, lane order within a sweep).
+__device__ __forceinline__ void emit_compact_from_words(const RxParams& p, const uint32_t* src, uint32_t stream, uint32_t lane) {
+  uint32_t mine = 0;
+  for (uint32_t w = lane; w < p.nw32; w += 64u) mine += (uint32_t)__popc(src[w]);
+  uint32_t total = mine;
+  for (int d = 32; d >= 1; d >>= 1) total += (uint32_t)__shfl_xor((int)total, d);
+  unsigned long long base = 0;
+  if (lane == 0 && total) base = atomicAdd(p.fin_count, (unsigned long long)total);
+  base = ((unsigned long long)bcast((uint32_t)(base >> 32), 0) << 32) | bcast((uint32_t)base, 0);
+  if (lane == 0) {
+    p.fin_off[stream] = (uint32_t)(base < p.fin_cap ? base : p.fin_cap);
+    p.fin_cnt[stream] = total;
+  }
+  unsigned long long at = base;
+  for (uint32_t w0 = 0; w0 < p.nw32 && total; w0 += 64u) {
+    const uint32_t w = w0 + lane;
+    uint32_t bits = w < p.nw32 ? src[w] : 0u;
+    const uint32_t n = (uint32_t)__popc(bits);
+    uint32_t incl = n;  // inclusive prefix sum over the lanes
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t v = (uint32_t)__shfl_up((int)incl, d);
+      if (lane >= (uint32_t)d) incl += v;
+    }
+    unsigned long long o = at + (incl - n);
+    while (bits) {
+      const uint32_t bpos = (uint32_t)__builtin_ctz(bits);
+      bits &= bits - 1u;
+      if (o < p.fin_cap) p.fin_states[o] = w * 32u + bpos;
+      o++;
+    }
+    at += bcast(incl, 63);
+  }
+}
+
 __device__ __forceinline__ void stream_store_final(const RxParams& p, StreamState& st, uint32_t stream,
                                                    uint32_t lane) {
-  if (!p.final_active) return;
+  if (!p.final_active && !p.fin_states) return;
   uint32_t* row = p.final_active + (size_t)stream * p.nw64x2;
   uint32_t* src = st.cb;
   if (!st.dense) {  // rebuild the bitmask from the list in the (all-zero) filter
@@ -215,7 +250,9 @@ __device__ __forceinline__ void stream_store_final(const RxParams& p, StreamStat
     src = st.nb;
     wave_sync();
   }
-  for (uint32_t w = lane; w < p.nw64x2; w += 64u) row[w] = w < p.nw32 ? src[w] : 0u;
+  if (p.fin_states) emit_compact_from_words(p, src, stream, lane);
+  else
+    for (uint32_t w = lane; w < p.nw64x2; w += 64u) row[w] = w < p.nw32 ? src[w] : 0u;
   wave_sync();
   if (!st.dense)
     for (uint32_t i = lane; i < st.n_cur; i += 64u) st.nb[(st.clist[i] & RXE_TGT_MASK) >> 5] = 0u;
@@ -870,8 +907,11 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
   const uint32_t stream0 = wave * S;
   if (stream0 >= p.n_streams) return;
   const uint32_t n_mine = p.n_streams - stream0 < (uint32_t)S ? p.n_streams - stream0 : (uint32_t)S;
-  const bool owner = lane < n_mine;  // lane == stream slot it owns
-  zero_final_rows(p, stream0, n_mine, lane);
+  // Stream slots this wavefront still handles (wave-uniform): a stream whose active set makes the wave-wide list overflow
+  // is handed to the wave kernel ALONE (evict, below) and its slot goes idle; the others stay.
+  unsigned long long alive = n_mine >= 64u ? ~0ull : (1ull << n_mine) - 1ull;
+  bool owner = lane < n_mine;  // lane == stream slot it owns (and still handles)
+  bool replay = false;         // the pass is being run again after an eviction: its accept pulses are out already
   // input windows: lane = 4*slot + part fetches bytes [64*chunk + 16*part, +16) of stream `slot`
   static_assert(S >= 1 && S <= (FOLD ? 64 : 32), "five-bit (FOLD: six-bit) stream slot; the window loader covers 16 streams per wave-load");
   constexpr uint32_t NLOAD = (S + 15) / 16;  // wave-loads per refill
@@ -1089,7 +1129,7 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
       uint32_t* sreg = sreg0 + sid * L::STRIDE;
       {  // accept pulses
         const uint64_t ma = wballot((e & (E_NONE | RXE_ACCEPT)) == RXE_ACCEPT);
-        if (__builtin_expect(ma != 0, 0)) {  // the common pass has no accept state: keep it the fall-through path
+        if (__builtin_expect(ma != 0 && !replay, 0)) {  // the common pass has no accept state: keep it the fall-through path
           const bool acc = (e & (E_NONE | RXE_ACCEPT)) == RXE_ACCEPT;
           uint32_t dummy = 0;
           emit_events(p, acc, s, stream0 + sid, k, lane, dummy);
@@ -1104,7 +1144,7 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
       // zero the filter word this entry went through (lanes without an entry hit some word of the CURRENT filter of
       // a valid slot; that filter is being wiped this pass anyway and is not read before the next swap)
       if (!RX_AB_PREDICATE_IDLE || li < Ns) sreg[fcur_off + ((s & HMASK) >> 5)] = 0u;
-      if (STATS && (e & E_NONE) == 0u) {
+      if (STATS && !replay && (e & E_NONE) == 0u) {
         const uint32_t deg = rp[s + 1] - rp[s];
         st_active += 1;
         st_edges += deg;
@@ -1130,7 +1170,7 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
       uint32_t x = x_none;
       if (live)  // s < 2^24, ncls <= 256: the 24-bit multiply-add is a full-rate VALU op, v_mul_lo_u32 is quarter rate
         x = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(symidx) + ((__umul24(s, ncls) + c) << 2));
-      if (STATS) {
+      if (STATS && !replay) {
         if (x & RXE_OVF) st_ovf += 1;
         if ((e & MARK) && live && x == 0u) st_dead += 1;  // came out of a multi-target row and dies at once
       }
@@ -1234,38 +1274,69 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
     stamp(5);  // phase 5: overflow lists + loop control
     if (consume) {
       if (__builtin_expect(Nn > L::CAPW, 0)) {
-        // the wave-wide list cannot hold the next sets: hand ALL of this wave's streams (S_k, k) to the
-        // wave kernel.  S_k = the current list, still intact.
-        unsigned long long b = 0;
-        if (lane == 0) b = atomicAdd(p.spill_count, (unsigned long long)n_mine);
-        const uint32_t slot_base = bcast((uint32_t)b, 0);
+        // The wave-wide list cannot hold the next sets.  ONE stream leaves — the one with the most entries in the part of
+        // the next list that was written — with its S_k (its entries of the current list, still intact) and k, to be
+        // finished by the wave kernel; its slot goes idle.  The other streams run this pass again (replay: their accept
+        // pulses of pass k are out already, as are the leaving stream's, which the wave kernel therefore skips at k).
         wave_sync();
-        if (owner) {
-          const uint32_t slot = slot_base + lane;
-          slotw[lane] = slot;
-          p.spill_streams[slot] = stream0 + lane;
+        uint32_t c_next = 0;
+        {
+          const uint32_t lim = Nn < L::CAPW ? Nn : L::CAPW;
+          for (uint32_t q = 0; q < lim; q++) c_next += ((nlist[q] >> SID_SHIFT) & SID_BITS) == lane ? 1u : 0u;
+        }
+        uint32_t key = owner ? ((c_next + 1u) << 6) | (63u - lane) : 0u;  // most entries, lowest slot on ties; > 0 for every live slot
+        for (int d = 32; d >= 1; d >>= 1) {
+          const uint32_t o = (uint32_t)__shfl_xor((int)key, d);
+          key = o > key ? o : key;
+        }
+        const uint32_t v = 63u - (key & 63u);  // wave-uniform (every lane holds the maximum)
+        unsigned long long b = 0;
+        if (lane == 0) b = atomicAdd(p.spill_count, 1ull);
+        const uint32_t slot = bcast((uint32_t)b, 0);
+        uint32_t* row = p.spill_rows + (size_t)slot * p.nw64x2;
+        for (uint32_t w = lane; w < p.nw64x2; w += 64u) row[w] = 0u;
+        if (lane == v) {
+          p.spill_streams[slot] = stream0 + v;
           p.spill_k[slot] = k;
           if (p.anymatch)
-            p.anymatch[(size_t)(stream0 + lane) * p.anymatch_stride + (k >> 5)] = sreg0[lane * L::STRIDE + 2u * L::FW + L::WINW];
-          uint32_t* row = p.spill_rows + (size_t)slot * p.nw64x2;
-          for (uint32_t w = 0; w < p.nw64x2; w++) row[w] = 0u;
-          if (FOLD && k >= 1u) row[p.pin_state >> 5] = 1u << (p.pin_state & 31u);  // S_k holds the folded state
+            p.anymatch[(size_t)(stream0 + v) * p.anymatch_stride + (k >> 5)] = sreg0[v * L::STRIDE + 2u * L::FW + L::WINW];
         }
         __threadfence();
         wave_sync();
-        for (uint32_t li = lane; li < N; li += 64u) {
-          const uint32_t e = clist[li];
-          const uint32_t sq = e & RXE_TGT_MASK;
-          uint32_t* row = p.spill_rows + (size_t)slotw[(e >> SID_SHIFT) & SID_BITS] * p.nw64x2;
-          atomicOr(&row[sq >> 5], 1u << (sq & 31u));
+        // S_k of the leaving stream into its hand-off row; the list without it into the other buffer
+        uint32_t M = 0;
+        for (uint32_t b0 = 0; b0 < N; b0 += 64u) {
+          const uint32_t li = b0 + lane;
+          const uint32_t e = li < N ? clist[li] : 0u;
+          const bool mine_v = li < N && ((e >> SID_SHIFT) & SID_BITS) == v;
+          if (mine_v) {
+            const uint32_t sq = e & RXE_TGT_MASK;
+            atomicOr(&row[sq >> 5], 1u << (sq & 31u));
+          }
+          const bool keep = li < N && !mine_v;
+          const uint64_t mk = wballot(keep);
+          if (keep) nlist[rank_below_plus(mk, M)] = e;
+          M += (uint32_t)__popcll(mk);
         }
-        spilled = true;
+        if (FOLD && k >= 1u && lane == 0) atomicOr(&row[p.pin_state >> 5], 1u << (p.pin_state & 31u));  // S_k holds the folded state
+        {
+          uint32_t* t = clist; clist = nlist; nlist = t;
+        }
+        N = M;
+        // both filters of every slot start clean (bits of entries that were counted but not written would otherwise stay)
+        for (uint32_t w = lane; w < (uint32_t)S * 2u * L::FW; w += 64u) sreg0[(w / (2u * L::FW)) * L::STRIDE + (w % (2u * L::FW))] = 0u;
+        alive &= ~(1ull << v);
+        owner = lane < n_mine && ((alive >> lane) & 1ull) != 0ull;
+        replay = true;
+        if (alive == 0ull) spilled = true;  // nothing left here
+        wave_sync();
       } else {
         {  // current <- next (FPGA.v:733-737)
           uint32_t* t = clist; clist = nlist; nlist = t;
           const uint32_t f = fcur_off; fcur_off = fnext_off; fnext_off = f;
         }
         N = Nn;
+        replay = false;
         wave_sync();
       }
     }
@@ -1287,10 +1358,12 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
           if ((rest & 1ull) == 0ull) {
             const uint32_t skip = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
             k += skip < k32 - k ? skip : k32 - k;
+            replay = false;  // (a pass to be run again after an eviction that is a no-op for the streams that stayed)
             continue;
           }
         }
         pass(k, std::true_type{});
+        if (__builtin_expect(replay, 0)) continue;  // a stream was evicted: the same pass again for the others
         k++;
       } while (k < k32 && !spilled);
       if (!spilled && p.anymatch && (k & 31u) == 0u) store_anymatch((k >> 5) - 1u);
@@ -1309,16 +1382,83 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
     if (wave == 0) p.counters[15] = (((__builtin_amdgcn_s_memtime() - t0c) >> 6) << 32) | ((__builtin_amdgcn_s_memrealtime() - t0r) & 0xFFFFFFFFull);
   }
   if ((FOLD || PRUNE) && lane == 0 && fold_entries) atomicAdd(&p.counters[7], fold_entries);
-  // final active sets: the rows were zeroed at the start of this kernel; set the listed bits
-  if (p.final_active && !spilled) {
-    for (uint32_t li = lane; li < N; li += 64u) {
-      const uint32_t e = clist[li];
-      const uint32_t sq = e & RXE_TGT_MASK;
-      uint32_t* row = p.final_active + (size_t)(stream0 + ((e >> SID_SHIFT) & SID_BITS)) * p.nw64x2;
-      atomicOr(&row[sq >> 5], 1u << (sq & 31u));
+  // Final active sets of the streams that stayed (FPGA.v:733-737: the set that survives the last byte).  The next-list
+  // buffer is dead now and serves as scratch.
+  const bool pin_in = FOLD && n_consume >= 1u;  // the folded state is in every set after the first byte
+  if (p.fin_states && !spilled) {
+    // As compact lists, straight from the list entries — no bitmask row is ever built.  Per entry its rank among its
+    // stream's entries (ascending state), per stream (owner lane) the count and, FOLD, where the folded state goes; one
+    // atomic per wavefront for the space.
+    wave_sync();
+    uint32_t my_cnt = 0, pin_rank = 0;
+    for (uint32_t q = 0; q < N; q++) {
+      const uint32_t eq = clist[q];
+      const uint32_t sq = eq & RXE_TGT_MASK;
+      if (((eq >> SID_SHIFT) & SID_BITS) == lane && !(pin_in && sq == p.pin_state)) {
+        my_cnt++;
+        if (pin_in && sq < p.pin_state) pin_rank++;
+      }
     }
-    if (FOLD && owner && n_consume >= 1u)  // the folded state is in every set after the first byte
-      atomicOr(&p.final_active[(size_t)(stream0 + lane) * p.nw64x2 + (p.pin_state >> 5)], 1u << (p.pin_state & 31u));
+    if (!owner) my_cnt = 0;
+    else if (pin_in) my_cnt++;
+    uint32_t incl = my_cnt;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+      if (lane >= (uint32_t)d) incl += o;
+    }
+    const uint32_t total = bcast(incl, 63);
+    unsigned long long base = 0;
+    if (lane == 0 && total) base = atomicAdd(p.fin_count, (unsigned long long)total);
+    base = ((unsigned long long)bcast((uint32_t)(base >> 32), 0) << 32) | bcast((uint32_t)base, 0);
+    const unsigned long long my_off64 = base + (incl - my_cnt);
+    const uint32_t my_off = (uint32_t)(my_off64 < p.fin_cap ? my_off64 : p.fin_cap);
+    if (owner) {
+      p.fin_off[stream0 + lane] = my_off;
+      p.fin_cnt[stream0 + lane] = my_cnt;
+      if (pin_in && my_off + pin_rank < p.fin_cap) p.fin_states[my_off + pin_rank] = p.pin_state;
+    }
+    if (lane < (uint32_t)S) slotw[lane] = my_off;
+    wave_sync();
+    for (uint32_t b0 = 0; b0 < N; b0 += 64u) {
+      const uint32_t li = b0 + lane;
+      const uint32_t e = li < N ? clist[li] : 0u;
+      const uint32_t sid = (e >> SID_SHIFT) & SID_BITS, sq = e & RXE_TGT_MASK;
+      const bool valid = li < N && !(pin_in && sq == p.pin_state);
+      uint32_t rank = (pin_in && sq > p.pin_state) ? 1u : 0u;
+      for (uint32_t q = 0; q < N; q++) {
+        const uint32_t eq = clist[q];
+        rank += (((eq >> SID_SHIFT) & SID_BITS) == sid && (eq & RXE_TGT_MASK) < sq) ? 1u : 0u;
+      }
+      if (valid) {
+        const uint32_t o = slotw[sid] + rank;
+        if (o < p.fin_cap) p.fin_states[o] = sq;
+      }
+    }
+  } else if (p.final_active && !spilled) {
+    // As bitmask rows: each row is built in LDS (in slices of the scratch buffer's size for automata whose row is longer)
+    // and stored ONCE with 8-byte stores — no zeroing in the prologue, no global atomics.
+    constexpr uint32_t SLICE = L::LISTW & ~1u;
+    for (uint32_t sl = 0; sl < n_mine; sl++) {
+      if (((alive >> sl) & 1ull) == 0ull) continue;  // (wave-uniform) finished by the wave kernel
+      for (uint32_t w0 = 0; w0 < p.nw64x2; w0 += SLICE) {
+        const uint32_t nwords = p.nw64x2 - w0 < SLICE ? p.nw64x2 - w0 : SLICE;
+        wave_sync();
+        for (uint32_t w = lane; w < nwords; w += 64u) nlist[w] = 0u;
+        wave_sync();
+        for (uint32_t li = lane; li < N; li += 64u) {
+          const uint32_t e = clist[li];
+          const uint32_t wd = (e & RXE_TGT_MASK) >> 5;
+          if (((e >> SID_SHIFT) & SID_BITS) == sl && wd >= w0 && wd - w0 < nwords) atomicOr(&nlist[wd - w0], 1u << (e & 31u));
+        }
+        if (pin_in && lane == 0) {
+          const uint32_t wd = p.pin_state >> 5;
+          if (wd >= w0 && wd - w0 < nwords) atomicOr(&nlist[wd - w0], 1u << (p.pin_state & 31u));
+        }
+        wave_sync();
+        uint2* row8 = reinterpret_cast<uint2*>(p.final_active + (size_t)(stream0 + sl) * p.nw64x2 + w0);
+        for (uint32_t w = lane; w < nwords / 2u; w += 64u) row8[w] = make_uint2(nlist[2u * w], nlist[2u * w + 1u]);
+      }
+    }
   }
   if (STATS) {
     if (st_active) atomicAdd(&p.counters[1], st_active);

@@ -151,3 +151,47 @@ def test_struct_size_zero_is_the_abi1_layout(rx, orx, traces, snort):
     assert r.n_events == ref["n_events"] and np.array_equal(ev[:r.n_events], ref["events"].astype(ev.dtype))
     assert int(r.stats.n_events) == ref["n_events"]
     assert bytes(buf)[abi1:] == b"\xC5" * (C.sizeof(h._Result) - abi1)
+
+
+def test_evictions_rows_and_compact_lists(rx, orx):
+    """Streams that outgrow the pack kernel's wave-wide list at different passes (or never) inside one wavefront: each
+    leaves ALONE (its neighbours stay on the pack kernel and run the pass again), and the final sets — as rows written
+    once from LDS, and as compact lists written by the match kernels themselves — equal the oracle's, as do events and
+    the any-match bitmap.  Plain, pruned and FOLD builds, few and many streams per wavefront."""
+    import sys
+    sys.path.insert(0, __import__("os").path.dirname(__file__))
+    from nfa_util import late_blowup_nfa
+    W, size = late_blowup_nfa(220)
+    nfa = rx.Nfa.from_words(W)
+    base = b"xabxab..abYab"
+    ns, sl = 333, 160
+    rows = np.zeros((ns, sl), np.uint8)
+    for s in range(ns):
+        txt = bytearray((base * 16)[:sl])
+        if s % 5 in (1, 3):                  # two in five blow up, at different passes; some come back down ('B')
+            at = 5 + (s * 7) % 120
+            txt[at:at + 6] = b"ZYYYab" if s % 2 else b"ZYYBab"
+        rows[s] = np.frombuffer(bytes(txt), np.uint8)
+    ref = orx.match_batch(W, size, rows)
+    assert ref["stats"]["max_active"] > 200 and ref["n_events"] > 1000
+    n_fin = int(np.unpackbits(ref["final_active"].view(np.uint8)).sum())
+    H = rx.host
+    for kw in (dict(kernel=rx.KERNEL_AUTO), dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=13), dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=4),
+               dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=32), dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=16, flags=H.OPT_FORCE_FOLD),
+               dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=64, flags=H.OPT_FORCE_FOLD | H.OPT_FORCE_PRUNE),
+               dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=8, flags=H.OPT_FORCE_PRUNE), dict(kernel=rx.KERNEL_SYM_WAVE),
+               dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=4), dict(kernel=rx.KERNEL_SYM_REG)):
+        p = rx.Plan(nfa, ns, sl, events_cap=1 << 20, **kw)
+        got = p.run(rows)
+        assert got["n_events"] == ref["n_events"] and np.array_equal(got["events"], ref["events"].astype(got["events"].dtype)), kw
+        assert np.array_equal(got["final_active"], ref["final_active"]), kw
+        assert np.array_equal(got["anymatch"][:, :ref["anymatch"].shape[1]], ref["anymatch"]), kw
+        got = p.run(rows, compact_final=n_fin)
+        assert not got["final_states_overflow"] and len(got["final_states"]) == n_fin, kw
+        assert np.array_equal(H.expand_final(got, nfa.nw64), ref["final_active"]), kw
+        for s in range(ns):  # ascending within every stream
+            st = got["final_states"][got["final_off"][s]:got["final_off"][s] + got["final_cnt"][s]]
+            assert np.all(st[1:] > st[:-1]), (kw, s)
+        got = p.run(rows, compact_final=max(n_fin // 2, 1))  # capacity too small: counts exact, nothing written beyond it
+        assert got["final_states_overflow"] and int(got["final_cnt"].sum()) == n_fin, kw
+        p.close()
