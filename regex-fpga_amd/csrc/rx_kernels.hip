@@ -894,6 +894,8 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
   const bool narrow = PRUNE && p.prune_narrow != 0u;
   const uint32_t xtmask = narrow ? 0xFFFFu : RXE_TGT_MASK;
   const uint32_t ncls = p.n_classes;
+  uint32_t ncls_v = ncls;  // the same in a VGPR: a VALU instruction with an SGPR operand issues at half rate
+  asm volatile("" : "+v"(ncls_v));
   const uint32_t* __restrict__ ovf = p.ovf;
   unsigned long long st_active = 0, st_edges = 0, st_cost = 0, st_ovf = 0, st_dead = 0, fold_entries = 0;
 
@@ -909,9 +911,12 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
   const uint32_t n_mine = p.n_streams - stream0 < (uint32_t)S ? p.n_streams - stream0 : (uint32_t)S;
   // Stream slots this wavefront still handles (wave-uniform): a stream whose active set makes the wave-wide list overflow
   // is handed to the wave kernel ALONE (evict, below) and its slot goes idle; the others stay.
-  unsigned long long alive = n_mine >= 64u ? ~0ull : (1ull << n_mine) - 1ull;
+  // (n_mine comes from threadIdx.x >> 6, which the compiler cannot know to be the same in all 64 lanes: one readfirstlane
+  // here keeps `alive`, and with it the loop conditions below, in SGPRs)
+  const uint32_t n_mine_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_mine);
+  unsigned long long alive = n_mine_s >= 64u ? ~0ull : (1ull << n_mine_s) - 1ull;
   bool owner = lane < n_mine;  // lane == stream slot it owns (and still handles)
-  bool replay = false;         // the pass is being run again after an eviction: its accept pulses are out already
+  uint32_t replay = 0u;        // 1: the pass is being run again after an eviction (its accept pulses are out already); scalar
   // input windows: lane = 4*slot + part fetches bytes [64*chunk + 16*part, +16) of stream `slot`
   static_assert(S >= 1 && S <= (FOLD ? 64 : 32), "five-bit (FOLD: six-bit) stream slot; the window loader covers 16 streams per wave-load");
   constexpr uint32_t NLOAD = (S + 15) / 16;  // wave-loads per refill
@@ -941,10 +946,15 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
 
   for (uint32_t w = lane; w < S * L::STRIDE; w += 64u) sreg0[w] = 0u;
   if (owner) wl[lane] = p.state0_entry | (lane << SID_SHIFT);  // FPGA.v:134-147: current = {state 0}, per stream
-  uint32_t N = n_mine, Nn = 0;
+  uint32_t N = n_mine_s, Nn = 0;  // (scalar: see n_mine_s)
   uint32_t* clist = wl;              // the two wave-wide lists and the two filter halves swap roles every pass
   uint32_t* nlist = wl + L::LISTW;
-  uint32_t fcur_off = 0, fnext_off = L::FW;
+  // the two filter halves of a stream region, as BYTE offsets (carried in VGPRs and added with plain v_add: a word offset
+  // would be scaled by a three-operand v_lshl_add in every sweep, which issues at half rate)
+  uint32_t fcur_b = 0, fnext_b = L::FW * 4u;
+  auto fword = [](uint32_t* sreg, uint32_t half_b, uint32_t h) -> uint32_t* {
+    return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(sreg) + half_b + ((h >> 5) << 2));
+  };
   uint32_t nxt[NLOAD][4];
   load_win(0, nxt);
   wave_sync();
@@ -952,8 +962,9 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
   // A lane without an entry still runs the unpredicated LDS operations of a pass (zero stores into the filter being
   // wiped, OR 0 into the filter being filled): its pseudo entry points every lane at a different (slot, filter word)
   // so that those no-ops do not pile up on one LDS address.
-  const uint32_t x_none = (lane / (uint32_t)S) << 5;
-  const uint32_t e_none = 0x80000000u | ((lane % (uint32_t)S) << SID_SHIFT) | x_none;
+  // (Its state id is `size`: the row behind the last state's in the slice index, all zero — idle lanes gather like
+  // everybody else, no EXEC masking, and find nothing; so do accept states, whose rows are empty by definition.)
+  const uint32_t e_none = 0x80000000u | ((lane % (uint32_t)S) << SID_SHIFT) | p.size;
 
   unsigned long long busy = ~0ull;  // FOLD: bit j = pass j of the current window has an emission of the folded state (wave-uniform)
   // window refill at a pass k that is a multiple of 64: bytes -> byte classes on the way into LDS, next window requested
@@ -1066,7 +1077,7 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
       const uint32_t h = t & HMASK;
       const uint32_t bit = 1u << (h & 31u);
       uint32_t old = 0;
-      if (pred) old = atomicOr(&sreg[fnext_off + (h >> 5)], bit);
+      if (pred) old = atomicOr(fword(sreg, fnext_b, h), bit);
       const bool fresh = pred && (old & bit) == 0;
       const bool maybe = pred && (old & bit) != 0;
       const uint64_t mf = wballot(fresh);
@@ -1119,31 +1130,35 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
     constexpr uint32_t E_NONE = 0x80000000u;  // list-entry flag of a lane without an entry (bit 31 is otherwise unused)
     const uint32_t Ns = (uint32_t)__builtin_amdgcn_readfirstlane((int)N);  // wave-uniform: keep the loop scalar
     if ((FOLD || PRUNE) && consume) fold_entries += Ns;  // (scalar) what AUTO's probe reads: list entries left per stream-byte
-    for (uint32_t b0 = 0; b0 < Ns; b0 += 64u) {
-      const uint32_t li = b0 + lane;
-      uint32_t e = clist[li];  // lanes past N read harmless LDS words of this wave and are overwritten below
-      if (li >= Ns) e = e_none;
+    const uint32_t* cp = clist + lane;  // this lane's entry of the sweep (a carried address: no index arithmetic per sweep)
+    for (uint32_t b0 = 0; b0 < Ns; b0 += 64u, cp += 64) {
+      const bool have = lane < Ns - b0;  // (scalar subtraction, one v_cmp)
+      uint32_t e = *cp;  // lanes past N read harmless LDS words of this wave and are overwritten below
+      if (!have) e = e_none;
       if (PROF) { asm volatile("" ::"v"(e)); stamp(0); }  // phase 0: refill check + list read
       const uint32_t sid = (e >> SID_SHIFT) & SID_BITS;
       const uint32_t s = e & RXE_TGT_MASK;
       uint32_t* sreg = sreg0 + sid * L::STRIDE;
-      {  // accept pulses
-        const uint64_t ma = wballot((e & (E_NONE | RXE_ACCEPT)) == RXE_ACCEPT);
-        if (__builtin_expect(ma != 0 && !replay, 0)) {  // the common pass has no accept state: keep it the fall-through path
-          const bool acc = (e & (E_NONE | RXE_ACCEPT)) == RXE_ACCEPT;
+      // accept pulses of the entries that are accept states (FPGA.v:210-226); a lane without an entry never has the flag
+      auto accept_pulses = [&]() {
+        if (wballot(e & RXE_ACCEPT) != 0ull && !replay) {
+          const bool acc = (e & RXE_ACCEPT) != 0u;
           uint32_t dummy = 0;
           emit_events(p, acc, s, stream0 + sid, k, lane, dummy);
           if (acc) atomicOr(&sreg[2u * L::FW + L::WINW], 1u << (k & 31u));
         }
+      };
+      if (!consume) {  // RX_MODE_FULL's last pass: nothing but the pulses
+        accept_pulses();
+        continue;
       }
-      if (!consume) continue;
-      const bool live = (e & (E_NONE | RXE_ACCEPT)) == 0u;  // a real entry that is not an accept state: it has a row
+      const bool live = (e & (E_NONE | RXE_ACCEPT)) == 0u;  // a real entry that is not an accept state: it has a row (statistics only)
       const uint32_t c = reinterpret_cast<const uint8_t*>(sreg + 2u * L::FW)[kk];  // class of that stream's input_char
       uint32_t cnx = 0u;  // PRUNE: class of its NEXT byte (byte 64 of the window: the stash)
       if (PRUNE) cnx = reinterpret_cast<const uint8_t*>(sreg + 2u * L::FW)[kk + 1u];
       // zero the filter word this entry went through (lanes without an entry hit some word of the CURRENT filter of
       // a valid slot; that filter is being wiped this pass anyway and is not read before the next swap)
-      if (!RX_AB_PREDICATE_IDLE || li < Ns) sreg[fcur_off + ((s & HMASK) >> 5)] = 0u;
+      if (!RX_AB_PREDICATE_IDLE || have) *fword(sreg, fcur_b, s & HMASK) = 0u;
       if (STATS && !replay && (e & E_NONE) == 0u) {
         const uint32_t deg = rp[s + 1] - rp[s];
         st_active += 1;
@@ -1167,9 +1182,8 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
       if (PROF) { asm volatile("" ::"v"(c)); stamp(1); }  // phase 1: accept check, window byte, filter clear
       // current byte's slice of row s; 32-bit byte offset from a scalar base (table < 4 GiB) keeps the address
       // arithmetic out of the 64-bit VALU path
-      uint32_t x = x_none;
-      if (live)  // s < 2^24, ncls <= 256: the 24-bit multiply-add is a full-rate VALU op, v_mul_lo_u32 is quarter rate
-        x = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(symidx) + ((__umul24(s, ncls) + c) << 2));
+      // s < 2^24, ncls <= 256: 24-bit multiply; every lane gathers (accept states and idle lanes read empty rows)
+      const uint32_t x = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(symidx) + ((__umul24(s, ncls_v) + c) << 2));
       if (STATS && !replay) {
         if (x & RXE_OVF) st_ovf += 1;
         if ((e & MARK) && live && x == 0u) st_dead += 1;  // came out of a multi-target row and dies at once
@@ -1188,29 +1202,43 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
       const uint32_t t1 = PRUNE ? (x & (xtmask | RXE_ACCEPT)) | (e_keep & ~T1_MASK)
                                 : (x & T1_MASK) | (e_keep & ~T1_MASK);  // v_bfi: a live e has only its slot bits outside the mask
       const uint32_t h0 = e & HMASK, h1 = x & HMASK;
-      const uint32_t v0 = (x & RXE_SELF) ? 1u << (h0 & 31u) : 0u;    // bit to set, 0 = no candidate
+      // bit to set, 0 = no candidate: flag bit shifted down to 0/1, then up by the hash (two plain shifts; a select on the
+      // flag would go through v_bfe_i32 + v_and, and three-operand VALU forms issue at half rate — DESIGN.md 3.4)
+      const uint32_t v0 = ((x >> 29) & 1u) << (h0 & 31u);
+      static_assert(RXE_SELF == (1u << 29) && RXE_INLINE == (1u << 31), "flag positions used as shift counts");
       // (FOLD: a target that IS the folded state is dropped — the stream holds it anyway)
       // (PRUNE, narrow index: an inline target that is no accept state and has no edge on the stream's next byte can neither
       // pulse nor produce a successor: it is not inserted — except at the stream's last byte, whose sets are reported)
       bool inl = FOLD ? (x & (RXE_INLINE | RXE_PIN)) == RXE_INLINE : (x & RXE_INLINE) != 0u;
       if (PRUNE) inl = inl && (((x | keep_all) >> (16u + (cnx & 7u))) & 1u) != 0u;
-      const uint32_t v1 = inl ? 1u << (h1 & 31u) : 0u;
+      const uint32_t v1 = (!PRUNE && !FOLD) ? (x >> 31) << (h1 & 31u) : (inl ? 1u << (h1 & 31u) : 0u);
       uint32_t o0 = 0u, o1 = 0u;
-      if (!RX_AB_PREDICATE_IDLE || v0) o0 = atomicOr(&sreg[fnext_off + (h0 >> 5)], v0);
-      if (!RX_AB_PREDICATE_IDLE || v1) o1 = atomicOr(&sreg[fnext_off + (h1 >> 5)], v1);
+      if (!RX_AB_PREDICATE_IDLE || v0) o0 = atomicOr(fword(sreg, fnext_b, h0), v0);
+      if (!RX_AB_PREDICATE_IDLE || v1) o1 = atomicOr(fword(sreg, fnext_b, h1), v1);
       __builtin_amdgcn_sched_barrier(0);  // keep the first result's consumers behind the second atomic's issue
       if (PROF) { asm volatile("" ::"v"(o0), "v"(o1)); stamp(3); }  // phase 3: the two filter atomics
       // fresh: candidate whose bit was clear; maybe: candidate whose bit was already set
-      const uint64_t mf0 = wballot((v0 & ~o0) != 0u), mf1 = wballot((v1 & ~o1) != 0u);
+      // (v is one bit or nothing, d = the part of it that was already set: fresh <=> v != d, and d is needed below anyway)
+      const uint32_t d0 = v0 & o0, d1 = v1 & o1;
+      const uint64_t mf0 = wballot(v0 != d0), mf1 = wballot(v1 != d1);
       if (__builtin_expect(Nn <= L::CAPW, 1)) {  // (wave-uniform) past that the pass ends in a hand-off anyway; keeps writes inside LISTW
-        if ((v0 & ~o0) != 0u) nlist[rank_below_plus(mf0, Nn)] = e_keep;
-        if ((v1 & ~o1) != 0u) nlist[rank_below_plus(mf1, Nn + (uint32_t)__popcll(mf0))] = t1;
+        if (v0 != d0) nlist[rank_below_plus(mf0, Nn)] = e_keep;
+        if (v1 != d1) nlist[rank_below_plus(mf1, Nn + (uint32_t)__popcll(mf0))] = t1;
       }
       Nn += (uint32_t)__popcll(mf0) + (uint32_t)__popcll(mf1);
-      if (__builtin_expect(wballot(((v0 & o0) | (v1 & o1)) != 0u) != 0, 0)) {  // rare
+      // Everything that is rare — an accept state among the entries, a candidate whose filter bit was already set, a row
+      // with several targets on the byte — hides behind ONE test (a v_cmp that writes a lane mask and the branch on it cost
+      // as much as four plain VALU instructions each: tools/issue_bench).
+      const uint32_t dup_bits = d0 | d1;
+      if (__builtin_expect(wballot(((e & RXE_ACCEPT) | (x & RXE_OVF) | dup_bits) != 0u) == 0ull, 1)) {
+        stamp(4);
+        continue;
+      }
+      accept_pulses();
+      if (wballot(dup_bits != 0u) != 0ull) {
         wave_sync();
-        resolve((v0 & o0) != 0u, e_keep);
-        resolve((v1 & o1) != 0u, t1);
+        resolve(d0 != 0u, e_keep);
+        resolve(d1 != 0u, t1);
       }
       stamp(4);  // phase 4: ballots, slots, list writes, rare duplicate resolution
       // rows with several targets on this byte (rare on snort_16, every pass on l7 and on compiled rule sets):
@@ -1289,7 +1317,9 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
           const uint32_t o = (uint32_t)__shfl_xor((int)key, d);
           key = o > key ? o : key;
         }
-        const uint32_t v = 63u - (key & 63u);  // wave-uniform (every lane holds the maximum)
+        // (every lane holds the maximum; through an SGPR so that everything derived from it — the set of live slots, the
+        // loop conditions — stays scalar for the compiler too)
+        const uint32_t v = 63u - ((uint32_t)__builtin_amdgcn_readfirstlane((int)key) & 63u);
         unsigned long long b = 0;
         if (lane == 0) b = atomicAdd(p.spill_count, 1ull);
         const uint32_t slot = bcast((uint32_t)b, 0);
@@ -1327,16 +1357,16 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
         for (uint32_t w = lane; w < (uint32_t)S * 2u * L::FW; w += 64u) sreg0[(w / (2u * L::FW)) * L::STRIDE + (w % (2u * L::FW))] = 0u;
         alive &= ~(1ull << v);
         owner = lane < n_mine && ((alive >> lane) & 1ull) != 0ull;
-        replay = true;
+        replay = 1u;
         if (alive == 0ull) spilled = true;  // nothing left here
         wave_sync();
       } else {
         {  // current <- next (FPGA.v:733-737)
           uint32_t* t = clist; clist = nlist; nlist = t;
-          const uint32_t f = fcur_off; fcur_off = fnext_off; fnext_off = f;
+          const uint32_t f = fcur_b; fcur_b = fnext_b; fnext_b = f;
         }
         N = Nn;
-        replay = false;
+        replay = 0u;
         wave_sync();
       }
     }
@@ -1358,13 +1388,12 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
           if ((rest & 1ull) == 0ull) {
             const uint32_t skip = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
             k += skip < k32 - k ? skip : k32 - k;
-            replay = false;  // (a pass to be run again after an eviction that is a no-op for the streams that stayed)
+            replay = 0u;  // (a pass to be run again after an eviction that is a no-op for the streams that stayed)
             continue;
           }
         }
         pass(k, std::true_type{});
-        if (__builtin_expect(replay, 0)) continue;  // a stream was evicted: the same pass again for the others
-        k++;
+        k += 1u - replay;  // (a stream was evicted: the same pass again for the others)
       } while (k < k32 && !spilled);
       if (!spilled && p.anymatch && (k & 31u) == 0u) store_anymatch((k >> 5) - 1u);
       if (LOOK && (k & 63u) == 32u) stash_next_first();
