@@ -137,8 +137,9 @@ def lib():
     L.rx_plan_set_device_input.argtypes = [vp, vp, sz, sz, sz]
     L.rx_plan_set_init_active.argtypes = [vp, vp]
     L.rx_plan_launch.argtypes = [vp]
-    L.rx_plan_tune.argtypes = [vp]
-    L.rx_plan_busy.argtypes = [vp, C.POINTER(u32)]
+    if hasattr(L, "rx_plan_tune"):  # (an older build loaded through RX_LIBRARY_PATH for an A/B run has neither)
+        L.rx_plan_tune.argtypes = [vp]
+        L.rx_plan_busy.argtypes = [vp, C.POINTER(u32)]
     L.rx_plan_sync.argtypes = [vp, C.POINTER(C.c_double)]
     L.rx_plan_kernel_times.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                        C.POINTER(C.c_double)]

@@ -124,8 +124,8 @@ def ruleset_traffic(pats, n_streams, stream_len, first=0, seed=7, workers=1):
 # ---- hand-off mix (bench.py `handoff_mix_T`): what one stream costs whose active set outgrows the pack kernel's list ----
 # No input makes ONE snort_16 stream hold more than a few dozen states (the shipped hi trace peaks at 37), so the
 # mechanism is measured on the shipped table with a trap grafted on: the `.*` state 1 enters a gate state on byte 0x00, the
-# gate enters `width` states on a second 0x00, and those keep each other alive on 0x00 and fall into a new accept state on
-# 0x01.  The byte pair (0x00, 0x00) occurs nowhere in the shipped traces, so trace windows never enter the trap.
+# gate enters `width` states on a second 0x00, and those loop on 0x00 and fall into a new accept state on 0x01.  The byte
+# pair (0x00, 0x00) occurs nowhere in the shipped traces, so trace windows never enter the trap.
 def table_with_trap(words, size, width=220):
     """-> (words', size') in the .coe layout: the automaton `words` plus gate, `width` trap states and one accept state."""
     W = np.asarray(words, np.uint32)
@@ -135,8 +135,8 @@ def table_with_trap(words, size, width=220):
     gate, first, acc = size, size + 1, size + 1 + width
     new_size = size + width + 2
     wide = np.arange(first, first + width, dtype=np.int64)
-    e_src = [src, np.array([1], np.int64), np.full(width, gate, np.int64), wide, wide, wide]
-    e_col = [col.astype(np.int64), np.array([gate], np.int64), wide, wide, np.roll(wide, -1), (1 << 24) | np.full(width, acc, np.int64)]
+    e_src = [src, np.array([1], np.int64), np.full(width, gate, np.int64), wide, wide]
+    e_col = [col.astype(np.int64), np.array([gate], np.int64), wide, wide, (1 << 24) | np.full(width, acc, np.int64)]
     s_all, c_all = np.concatenate(e_src), np.concatenate(e_col)
     order = np.argsort(s_all, kind="stable")
     s_all, c_all = s_all[order], c_all[order]
