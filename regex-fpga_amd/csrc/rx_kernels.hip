@@ -828,13 +828,14 @@ __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
 //     only the targets that survive the stream's next byte;
 //   * next list would exceed the layout's CAPW => all S streams are handed to the wave kernel (resume);
 //   * the passes run in chunked loops (refill per 64, bitmap store per 32, mode as a compile-time tag).
-template <int S, bool PRUNE, bool FOLD>
+template <int S, bool PRUNE, bool FOLD, bool LT = false>
 struct PackLayout {
   // few streams per wavefront = automata/inputs with many active states per stream: longer list, wider filters
   // (FOLD builds keep the always-on state out of the lists: about one entry per stream is left, half the filter does)
   static constexpr uint32_t FW = S <= 4 ? 2u * RX_GROUP_FILTER_WORDS : (FOLD ? RX_GROUP_FILTER_WORDS / 2u : RX_GROUP_FILTER_WORDS);
   // (the PRUNE build serves automata with bursts of active states: twice the list for up to 13 streams per wavefront)
-  static constexpr uint32_t CAPW = S <= 4 ? 512u : (PRUNE && S <= 13 ? 2u * RX_PACK_CAP : (S >= 48 ? 256u : RX_PACK_CAP));
+  // (LT builds keep the state table in the block's LDS next to sixteen wavefronts: a shorter list pays for it)
+  static constexpr uint32_t CAPW = LT ? 128u : S <= 4 ? 512u : (PRUNE && S <= 13 ? 2u * RX_PACK_CAP : (S >= 48 ? 256u : RX_PACK_CAP));
   // 64 input bytes (as byte classes) per stream; look-ahead builds (PRUNE, FOLD): + byte 64 = first class of the next
   // chunk (look-ahead at the window's last byte) + a pad word that keeps the stride odd
   static constexpr uint32_t WINW = (PRUNE || FOLD) ? 18 : 16;
@@ -856,9 +857,15 @@ struct PackLayout {
 // from pass 1 on, and what its row emits on the current byte comes from a (class x next class) table in LDS, looked
 // up by the stream's OWNER lane while the list entries' slice gather is in flight; of its targets only those that are
 // accept states or survive the next byte are inserted.  Six-bit stream slots (up to 64 streams per wavefront).
-template <int S, bool STATS, bool PROF, bool PRUNE, bool FOLD>
-__global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxParams p) {
+// LT: the state table in LDS (RxParams::lt_tab, rx_host.cpp).  The wait for the slice gather is the longest link of a pass —
+// ~900 cycles with twenty wavefronts per CU queueing at the vector L1, although L2 itself answers in ~140 (profiles/
+// r03_issue_ceiling) — and 8 430 of snort_16's 9 514 states have edges on at most ONE byte class: their whole row is one
+// word.  A block of up to sixteen wavefronts shares {one word per state, the pinned `.*` state's full row} in LDS and reads
+// its slices from there (~100 cycles); only an entry whose state has edges on several classes still gathers from HBM.
+template <int S, bool STATS, bool PROF, bool PRUNE, bool FOLD, bool LT = false>
+__global__ void __launch_bounds__(LT ? 1024 : (FOLD ? 512 : 256)) rx_sym_pack_kernel(const RxParams p) {
   static_assert(!((PRUNE || FOLD) && (STATS || PROF)), "statistics / stamped builds run unpruned and unfolded");
+  static_assert(!(LT && (STATS || PROF || PRUNE || FOLD)), "the LDS-table build exists for the plain pass only");
   constexpr bool LOOK = PRUNE || FOLD;  // the window carries one byte of look-ahead
   constexpr uint32_t MARK = 1u << 29;  // STATS only: entry was inserted from a multi-target row
   unsigned long long t_prev = 0, t_sum[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -872,7 +879,7 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
       t_prev = t;
     }
   };
-  using L = PackLayout<S, PRUNE, FOLD>;
+  using L = PackLayout<S, PRUNE, FOLD, LT>;
   constexpr uint32_t HMASK = 32u * L::FW - 1u;
   constexpr uint32_t SID_SHIFT = 24, SID_BITS = FOLD ? 63u : 31u, SID_MASK = SID_BITS << SID_SHIFT;
   constexpr uint32_t KEY_MASK = RXE_TGT_MASK | SID_MASK;
@@ -881,7 +888,8 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
   const uint32_t wib = threadIdx.x >> 6, wpb = blockDim.x >> 6;
   uint32_t* cmapw = lds;                              // [64] byte -> class
   const uint8_t* cmap = reinterpret_cast<const uint8_t*>(cmapw);
-  const uint32_t pin_words = FOLD ? p.n_classes * p.pin_cols : 0u;
+  // (FOLD: the folding table; LT: one word per state + the all-zero word of state `size`, then the pinned state's row)
+  const uint32_t pin_words = FOLD ? p.n_classes * p.pin_cols : (LT ? p.size + 1u + p.n_classes : 0u);
   const uint32_t* pintab = lds + L::CMAPW;           // FOLD: [n_classes][n_classes + 1], shared by the block
   uint32_t* wl = lds + L::CMAPW + pin_words + (size_t)wib * L::WAVE_WORDS;  // [2][CAPW] wave-wide lists
   uint32_t* sreg0 = wl + 2u * L::LISTW;              // [S][STRIDE]: filters[2][FW], window[WINW], am word
@@ -903,6 +911,8 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
   for (uint32_t w = threadIdx.x; w < L::CMAPW; w += blockDim.x) cmapw[w] = p.byte_class[w];
   if (FOLD)
     for (uint32_t w = threadIdx.x; w < pin_words; w += blockDim.x) lds[L::CMAPW + w] = p.pin_tab[w];
+  if (LT)
+    for (uint32_t w = threadIdx.x; w < pin_words; w += blockDim.x) lds[L::CMAPW + w] = p.lt_tab[w];
   __syncthreads();  // the only block-wide barrier; the waves never meet again
 
   const uint32_t wave = blockIdx.x * wpb + wib;
@@ -1182,8 +1192,24 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
       if (PROF) { asm volatile("" ::"v"(c)); stamp(1); }  // phase 1: accept check, window byte, filter clear
       // current byte's slice of row s; 32-bit byte offset from a scalar base (table < 4 GiB) keeps the address
       // arithmetic out of the 64-bit VALU path
-      // s < 2^24, ncls <= 256: 24-bit multiply; every lane gathers (accept states and idle lanes read empty rows)
-      const uint32_t x = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(symidx) + ((__umul24(s, ncls_v) + c) << 2));
+      uint32_t x;
+      if (LT) {
+        // one LDS word: the state's only non-empty slice with its class in bits 27:20, or — for the pinned state — the word
+        // of class c of its full row, tagged the same way; x = the word if the tag is c, else nothing
+        const uint32_t* tw = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds) + (L::CMAPW << 2) +
+                                                               (s == p.pin_state ? ((p.size + 1u + c) << 2) : (s << 2)));
+        const uint32_t d = *tw;
+        const uint32_t t = d ^ (c << 20);
+        x = (t & RXLT_CLASS_MASK) ? 0u : t;
+        if (__builtin_expect(wballot((d >> 30) == 1u) != 0ull, 0)) {  // a state with edges on several classes: its row is in HBM only
+          if ((d >> 30) == 1u)
+            x = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(symidx) + ((__umul24(s, ncls_v) + c) << 2)) &
+                ~(RXE_PIN | RXE_MAYDUP);
+        }
+      } else {
+        // s < 2^24, ncls <= 256: 24-bit multiply; every lane gathers (accept states and idle lanes read empty rows)
+        x = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(symidx) + ((__umul24(s, ncls_v) + c) << 2));
+      }
       if (STATS && !replay) {
         if (x & RXE_OVF) st_ovf += 1;
         if ((e & MARK) && live && x == 0u) st_dead += 1;  // came out of a multi-target row and dies at once
@@ -2198,6 +2224,24 @@ static int launch_pack_as(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t
   return launch_one(rx_sym_pack_kernel<S, false, false, false, false>, p, g, wpb * 64u, lds, s);
 }
 
+// LT builds: one copy of the state table per block, as many wavefronts beside it as the LDS holds (up to sixteen)
+template <int S>
+static int launch_ltab(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s, size_t lds_per_cu) {
+  using L = PackLayout<S, false, false, true>;
+  const uint32_t fixed = L::CMAPW + p.size + 1u + p.n_classes;
+  const uint32_t waves = (p.n_streams + S - 1) / S;
+  uint32_t wpb = 16;
+  while (wpb > 1 && (size_t)(fixed + wpb * L::WAVE_WORDS) * 4u > lds_per_cu) wpb--;
+  if ((size_t)(fixed + wpb * L::WAVE_WORDS) * 4u > lds_per_cu) return (int)hipErrorInvalidValue;
+  // (no point in a block larger than the batch needs on its busiest CU)
+  const uint32_t cus = cfg.cu_count > 0 ? (uint32_t)cfg.cu_count : 256u;
+  const uint32_t need = (waves + cus - 1) / cus;
+  if (need < wpb) wpb = need ? need : 1u;
+  const uint32_t grid = (waves + wpb - 1) / wpb;
+  const uint32_t lds = (fixed + wpb * L::WAVE_WORDS) * 4u;
+  return launch_one(rx_sym_pack_kernel<S, false, false, false, false, true>, p, grid ? grid : 1u, wpb * 64u, lds, s);
+}
+
 template <int S>
 static int launch_pack(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s) {
   if (cfg.prune && !cfg.stats && p.symidx_p) return launch_pack_as<S, true>(p, cfg, s);
@@ -2274,6 +2318,13 @@ int rx_launch(const RxParams& p, const RxLaunchCfg& cfg, void* hip_stream) {
         else if (gl <= 32) e = launch_fold<32>(p, cfg, s, lds_cu);
         else if (gl <= 48) e = launch_fold<48>(p, cfg, s, lds_cu);
         else e = launch_fold<64>(p, cfg, s, lds_cu);
+      } else if (cfg.kernel == RX_KERNEL_SYM_PACK && cfg.ltab && !cfg.stats && !cfg.prune && p.lt_tab) {
+        const size_t lds_cu = cfg.lds_per_cu ? cfg.lds_per_cu : 160u * 1024u;
+        const uint32_t gl = cfg.group_lanes;  // nearest instantiated number of streams per wavefront
+        if (gl <= 8) e = launch_ltab<8>(p, cfg, s, lds_cu);
+        else if (gl <= 13) e = launch_ltab<13>(p, cfg, s, lds_cu);
+        else if (gl <= 16) e = launch_ltab<16>(p, cfg, s, lds_cu);
+        else e = launch_ltab<24>(p, cfg, s, lds_cu);
       } else if (cfg.kernel == RX_KERNEL_SYM_PACK) {
         if (cfg.group_lanes == 2) e = launch_pack<2>(p, cfg, s);
         else if (cfg.group_lanes == 4) e = launch_pack<4>(p, cfg, s);
