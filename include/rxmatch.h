@@ -177,8 +177,6 @@ enum {
   RX_OPT_REG_NO_SKIP = 64u, /* SYM_REG: the build that does not step over passes in which no state is active (A/B runs) */
   RX_OPT_INJECT_RUN_FAULT = 128u, /* test hook: rx_plan_run fails with RX_EHIP once block 0's kernels and copies are in
                                      flight — exercises the drain-before-error-return path                           */
-  RX_OPT_LDS_TABLE = 512u,  /* SYM_PACK: the build that keeps one word per state (its only non-empty slice) in LDS and reads
-                               the slices from there; automata below 2^20 states whose table fits beside the wavefronts */
   RX_OPT_NO_PROBE = 256u    /* RX_KERNEL_AUTO never probes inside rx_plan_launch / rx_plan_run: no sample launches, no
                                timed candidates, no stream synchronisation.  The decision is the one rx_plan_tune made
                                for the shape, or a default (SYM_PACK, 16 streams per wavefront; SYM_REG up to 4 streams) */

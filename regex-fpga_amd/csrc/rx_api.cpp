@@ -73,7 +73,6 @@ struct DevTables {
   uint32_t *symidx_p = nullptr, *ovf_dir = nullptr;  // look-ahead pruning tables (pack kernel), may stay null
   uint32_t* pin_tab = nullptr;                       // folding table of the pinned state (pack kernel), may stay null
   uint32_t* regidx = nullptr;                        // register kernel's index, may stay null (huge automata)
-  uint32_t* lt_tab = nullptr;                        // pack kernel's LDS table (one word per state), may stay null
   uint32_t* byte_class = nullptr;
   // lazy-DFA cache (allocated by the first RX_KERNEL_DFA launch)
   uint32_t *dfa_trans = nullptr, *dfa_pool = nullptr, *dfa_hash = nullptr, *dfa_hdr = nullptr;
@@ -182,7 +181,6 @@ extern "C" void rx_nfa_free(rx_nfa* nfa) {
     (void)hipFree(kv.second.ovf_dir);
     (void)hipFree(kv.second.pin_tab);
     (void)hipFree(kv.second.regidx);
-    (void)hipFree(kv.second.lt_tab);
     (void)hipFree(kv.second.byte_class);
     (void)hipFree(kv.second.dfa_trans);
     (void)hipFree(kv.second.dfa_pool);
@@ -260,7 +258,6 @@ static int get_dev_tables(const rx_nfa* cnfa, int device, DevTables* out) {
   if (!nfa->h.ovf_dir.empty() && (rc = upload_vec(nfa->h.ovf_dir, &t.ovf_dir))) return rc;
   if (!nfa->h.pin_tab.empty() && (rc = upload_vec(nfa->h.pin_tab, &t.pin_tab))) return rc;
   if (!nfa->h.regidx.empty() && (rc = upload_vec(nfa->h.regidx, &t.regidx))) return rc;
-  if (!nfa->h.lt_tab.empty() && (rc = upload_vec(nfa->h.lt_tab, &t.lt_tab))) return rc;
   {
     std::vector<uint32_t> bc(64);
     memcpy(bc.data(), nfa->h.byte_class, 256);
@@ -696,7 +693,6 @@ static void fill_common(rx_plan* p, RxParams& a) {
   a.byte_class = p->tab.byte_class;
   a.pin_tab = p->tab.pin_tab;
   a.regidx = p->tab.regidx;
-  a.lt_tab = p->tab.lt_tab;
   a.reg_tmask = h.reg_tmask;
   a.pin_cols = h.n_classes + 1u;
   a.n_classes = h.n_classes;
@@ -1063,9 +1059,6 @@ static int prepare_launch(rx_plan* p) {
   } else if (p->cfg.kernel == RX_KERNEL_SYM_PACK && p->cfg.group_lanes > 32) {
     p->cfg.group_lanes = 32;
   }
-  // the build with the state table in LDS: on request (RX_OPT_LDS_TABLE) when the automaton qualifies; plain pass only
-  p->cfg.ltab = (p->opts.flags & RX_OPT_LDS_TABLE) != 0 && p->tab.lt_tab != nullptr && p->cfg.kernel == RX_KERNEL_SYM_PACK &&
-                !p->cfg.fold && !p->cfg.stats && !p->have_init;
   p->cfg.verbose = (p->opts.flags & RX_OPT_VERBOSE) != 0;
   p->cfg.profile_pack = (p->opts.flags & RX_OPT_PROFILE_PACK) != 0;
   p->cfg.reg_skip = !(p->opts.flags & RX_OPT_REG_NO_SKIP) && (p->opts.kernel == RX_KERNEL_AUTO ? p->auto_reg_skip : true);

@@ -407,23 +407,6 @@ int rxh_build(const uint32_t* W, size_t nwords, uint32_t size_or_0, RxHostNfa* o
           if ((w & RXE_INLINE) && dup(w & RXE_TGT_MASK, k)) w |= RXE_MAYDUP;
           if (w & RXE_OVF) flag_list(w & RXE_TGT_MASK, k);
         }
-    // ---- the pack kernel's LDS table (RxParams::lt_tab): one word per state ----------------------------------------------
-    out->lt_tab.clear();
-    if (size + 1u < (1u << 20) && out->ovf.size() < ((size_t)1 << 20)) {
-      out->lt_tab.assign((size_t)size + 1u + ncls, 0u);
-      for (uint32_t i = 0; i < size; i++) {
-        uint32_t n = 0, kk = 0, ww = 0;
-        for (uint32_t k = 0; k < ncls; k++) {
-          const uint32_t w = out->symidx_c[(size_t)i * ncls + k];
-          if (w != 0u) { n++; kk = k; ww = w; }
-        }
-        if (n == 1) out->lt_tab[i] = (ww & ~RXLT_CLASS_MASK) | (kk << 20);
-        else if (n > 1) out->lt_tab[i] = RXLT_FULL;
-      }
-      if (out->pin_state != 0xFFFFFFFFu)
-        for (uint32_t k = 0; k < ncls; k++)
-          out->lt_tab[(size_t)size + 1u + k] = (out->symidx_c[(size_t)out->pin_state * ncls + k] & ~RXLT_CLASS_MASK) | (k << 20);
-    }
     // ---- the register kernel's index: the in-place update of a lane precomputed per (state, class) ------------------
     out->regidx.clear();
     out->reg_tmask = RXE_TGT_MASK;

@@ -32,10 +32,6 @@ static constexpr uint32_t RXR_EXTRA = 0x20000000u; //   the state stays AND has 
 static constexpr uint32_t RXR_DUPC = 0x10000000u;  //   its one target may already be in the next set (RXE_MAYDUP): check, then a free lane
 static constexpr uint32_t RXR_OVFL = 0x08000000u;  //   several targets on the byte (overflow list in the slice word)
 static constexpr uint32_t RXE_TGT_MASK = 0x00FFFFFFu;
-static constexpr uint32_t RXLT_CLASS_MASK = 0x0FF00000u;  // lt_tab word: byte class the slice belongs to
-// lt_tab word of a state with edges on several classes (its slices stay in symidx_c): RXE_ACCEPT without RXE_INLINE, a
-// combination no slice word has; the kernel tests (word >> 30) == 1
-static constexpr uint32_t RXLT_FULL = RXE_ACCEPT;
 
 // Active-list entry (LDS): state id in bits 23:0, RXE_ACCEPT if the state is an accept state.
 
@@ -76,12 +72,6 @@ struct RxParams {
   // folding table has it for the folded state's.  reg_tmask = 0xFFFFFF otherwise (bits 23:0 value, no look-ahead).
   const uint32_t* regidx;
   uint32_t reg_tmask;
-  // LDS-table build of the pack kernel (rx_host.cpp): [size + 1] words, one per state — the state's ONLY non-empty slice of
-  // the per-class index with that class in bits 27:20 (RXE_PIN / RXE_MAYDUP dropped, targets and overflow offsets are below
-  // 2^20), 0 for a state without edges (and for the extra state `size`), RXLT_FULL for a state with edges on several classes
-  // — then [n_classes] words: the pinned state's row, every word tagged with its own class.
-  // Null when the automaton does not qualify.
-  const uint32_t* lt_tab;
   const uint32_t* byte_class;   // [64] words = 256 bytes: class id of every input byte
   uint32_t n_classes;
   const uint32_t* ovf;          // overflow target lists of the slice index
@@ -168,7 +158,6 @@ struct RxLaunchCfg {
   bool verbose;            // rx_opts.flags & RX_OPT_VERBOSE: print the launch geometry
   bool reg_skip;           // SYM_REG: the build that steps over groups of passes in which nothing is active
   bool profile_pack;       // rx_opts.flags & RX_OPT_PROFILE_PACK: stamped diagnostic build of the pack kernel (S=16)
-  bool ltab;               // SYM_PACK: the build with the state table in LDS (needs RxParams::lt_tab)
 };
 
 // rx_kernels.hip
@@ -205,7 +194,6 @@ struct RxHostNfa {
   // RxParams::regidx; empty for automata whose table would exceed 256 MB (the register kernel is then not offered)
   std::vector<uint32_t> regidx;
   uint32_t reg_tmask = RXE_TGT_MASK;  // RxParams::reg_tmask
-  std::vector<uint32_t> lt_tab;       // RxParams::lt_tab; empty when the automaton does not qualify
   const uint32_t* row_ptr() const { return words.data(); }
   const uint32_t* col() const { return words.data() + size + 1; }
 };

@@ -828,14 +828,13 @@ __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
 //     only the targets that survive the stream's next byte;
 //   * next list would exceed the layout's CAPW => all S streams are handed to the wave kernel (resume);
 //   * the passes run in chunked loops (refill per 64, bitmap store per 32, mode as a compile-time tag).
-template <int S, bool PRUNE, bool FOLD, bool LT = false>
+template <int S, bool PRUNE, bool FOLD>
 struct PackLayout {
   // few streams per wavefront = automata/inputs with many active states per stream: longer list, wider filters
   // (FOLD builds keep the always-on state out of the lists: about one entry per stream is left, half the filter does)
   static constexpr uint32_t FW = S <= 4 ? 2u * RX_GROUP_FILTER_WORDS : (FOLD ? RX_GROUP_FILTER_WORDS / 2u : RX_GROUP_FILTER_WORDS);
   // (the PRUNE build serves automata with bursts of active states: twice the list for up to 13 streams per wavefront)
-  // (LT builds keep the state table in the block's LDS next to sixteen wavefronts: a shorter list pays for it)
-  static constexpr uint32_t CAPW = LT ? 128u : S <= 4 ? 512u : (PRUNE && S <= 13 ? 2u * RX_PACK_CAP : (S >= 48 ? 256u : RX_PACK_CAP));
+  static constexpr uint32_t CAPW = S <= 4 ? 512u : (PRUNE && S <= 13 ? 2u * RX_PACK_CAP : (S >= 48 ? 256u : RX_PACK_CAP));
   // 64 input bytes (as byte classes) per stream; look-ahead builds (PRUNE, FOLD): + byte 64 = first class of the next
   // chunk (look-ahead at the window's last byte) + a pad word that keeps the stride odd
   static constexpr uint32_t WINW = (PRUNE || FOLD) ? 18 : 16;
@@ -857,15 +856,9 @@ struct PackLayout {
 // from pass 1 on, and what its row emits on the current byte comes from a (class x next class) table in LDS, looked
 // up by the stream's OWNER lane while the list entries' slice gather is in flight; of its targets only those that are
 // accept states or survive the next byte are inserted.  Six-bit stream slots (up to 64 streams per wavefront).
-// LT: the state table in LDS (RxParams::lt_tab, rx_host.cpp).  The wait for the slice gather is the longest link of a pass —
-// ~900 cycles with twenty wavefronts per CU queueing at the vector L1, although L2 itself answers in ~140 (profiles/
-// r03_issue_ceiling) — and 8 430 of snort_16's 9 514 states have edges on at most ONE byte class: their whole row is one
-// word.  A block of up to sixteen wavefronts shares {one word per state, the pinned `.*` state's full row} in LDS and reads
-// its slices from there (~100 cycles); only an entry whose state has edges on several classes still gathers from HBM.
-template <int S, bool STATS, bool PROF, bool PRUNE, bool FOLD, bool LT = false>
-__global__ void __launch_bounds__(LT ? 1024 : (FOLD ? 512 : 256)) rx_sym_pack_kernel(const RxParams p) {
+template <int S, bool STATS, bool PROF, bool PRUNE, bool FOLD>
+__global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxParams p) {
   static_assert(!((PRUNE || FOLD) && (STATS || PROF)), "statistics / stamped builds run unpruned and unfolded");
-  static_assert(!(LT && (STATS || PROF || PRUNE || FOLD)), "the LDS-table build exists for the plain pass only");
   constexpr bool LOOK = PRUNE || FOLD;  // the window carries one byte of look-ahead
   constexpr bool PAIR = !PROF;          // lists longer than 64 entries: two sweeps interleaved (see the pass)
   constexpr uint32_t MARK = 1u << 29;  // STATS only: entry was inserted from a multi-target row
@@ -880,7 +873,7 @@ __global__ void __launch_bounds__(LT ? 1024 : (FOLD ? 512 : 256)) rx_sym_pack_ke
       t_prev = t;
     }
   };
-  using L = PackLayout<S, PRUNE, FOLD, LT>;
+  using L = PackLayout<S, PRUNE, FOLD>;
   constexpr uint32_t HMASK = 32u * L::FW - 1u;
   constexpr uint32_t SID_SHIFT = 24, SID_BITS = FOLD ? 63u : 31u, SID_MASK = SID_BITS << SID_SHIFT;
   constexpr uint32_t KEY_MASK = RXE_TGT_MASK | SID_MASK;
@@ -889,8 +882,7 @@ __global__ void __launch_bounds__(LT ? 1024 : (FOLD ? 512 : 256)) rx_sym_pack_ke
   const uint32_t wib = threadIdx.x >> 6, wpb = blockDim.x >> 6;
   uint32_t* cmapw = lds;                              // [64] byte -> class
   const uint8_t* cmap = reinterpret_cast<const uint8_t*>(cmapw);
-  // (FOLD: the folding table; LT: one word per state + the all-zero word of state `size`, then the pinned state's row)
-  const uint32_t pin_words = FOLD ? p.n_classes * p.pin_cols : (LT ? p.size + 1u + p.n_classes : 0u);
+  const uint32_t pin_words = FOLD ? p.n_classes * p.pin_cols : 0u;
   const uint32_t* pintab = lds + L::CMAPW;           // FOLD: [n_classes][n_classes + 1], shared by the block
   uint32_t* wl = lds + L::CMAPW + pin_words + (size_t)wib * L::WAVE_WORDS;  // [2][CAPW] wave-wide lists
   uint32_t* sreg0 = wl + 2u * L::LISTW;              // [S][STRIDE]: filters[2][FW], window[WINW], am word
@@ -912,8 +904,6 @@ __global__ void __launch_bounds__(LT ? 1024 : (FOLD ? 512 : 256)) rx_sym_pack_ke
   for (uint32_t w = threadIdx.x; w < L::CMAPW; w += blockDim.x) cmapw[w] = p.byte_class[w];
   if (FOLD)
     for (uint32_t w = threadIdx.x; w < pin_words; w += blockDim.x) lds[L::CMAPW + w] = p.pin_tab[w];
-  if (LT)
-    for (uint32_t w = threadIdx.x; w < pin_words; w += blockDim.x) lds[L::CMAPW + w] = p.lt_tab[w];
   __syncthreads();  // the only block-wide barrier; the waves never meet again
 
   const uint32_t wave = blockIdx.x * wpb + wib;
@@ -973,9 +963,8 @@ __global__ void __launch_bounds__(LT ? 1024 : (FOLD ? 512 : 256)) rx_sym_pack_ke
   // A lane without an entry still runs the unpredicated LDS operations of a pass (zero stores into the filter being
   // wiped, OR 0 into the filter being filled): its pseudo entry points every lane at a different (slot, filter word)
   // so that those no-ops do not pile up on one LDS address.
-  // (Its state id is `size`: the row behind the last state's in the slice index, all zero — idle lanes gather like
-  // everybody else, no EXEC masking, and find nothing; so do accept states, whose rows are empty by definition.)
-  const uint32_t e_none = 0x80000000u | ((lane % (uint32_t)S) << SID_SHIFT) | p.size;
+  const uint32_t x_none = (lane / (uint32_t)S) << 5;
+  const uint32_t e_none = 0x80000000u | ((lane % (uint32_t)S) << SID_SHIFT) | x_none;
 
   unsigned long long busy = ~0ull;  // FOLD: bit j = pass j of the current window has an emission of the folded state (wave-uniform)
   // window refill at a pass k that is a multiple of 64: bytes -> byte classes on the way into LDS, next window requested
@@ -1171,15 +1160,12 @@ __global__ void __launch_bounds__(LT ? 1024 : (FOLD ? 512 : 256)) rx_sym_pack_ke
       w.sid = (w.e >> SID_SHIFT) & SID_BITS;
       w.s = w.e & RXE_TGT_MASK;
       w.sreg = sreg0 + w.sid * L::STRIDE;
-      w.c = 0u;
-      w.cnx = 0u;
-      if (w.have) {  // (lanes without an entry sit out of the LDS reads, the filter clear and the gather: one EXEC region)
-        w.c = reinterpret_cast<const uint8_t*>(w.sreg + 2u * L::FW)[kk];  // class of that stream's input_char
-        // PRUNE: class of its NEXT byte (byte 64 of the window: the stash)
-        if (PRUNE) w.cnx = reinterpret_cast<const uint8_t*>(w.sreg + 2u * L::FW)[kk + 1u];
-        // zero the filter word this entry went through
-        *fword(w.sreg, fcur_b, w.s & HMASK) = 0u;
-      }
+      w.c = reinterpret_cast<const uint8_t*>(w.sreg + 2u * L::FW)[kk];  // class of that stream's input_char
+      w.cnx = 0u;  // PRUNE: class of its NEXT byte (byte 64 of the window: the stash)
+      if (PRUNE) w.cnx = reinterpret_cast<const uint8_t*>(w.sreg + 2u * L::FW)[kk + 1u];
+      // zero the filter word this entry went through (lanes without an entry hit some word of the CURRENT filter of
+      // a valid slot; that filter is being wiped this pass anyway and is not read before the next swap)
+      if (!RX_AB_PREDICATE_IDLE || w.have) *fword(w.sreg, fcur_b, w.s & HMASK) = 0u;
       if (STATS && !replay && (w.e & E_NONE) == 0u) {
         const uint32_t deg = rp[w.s + 1] - rp[w.s];
         st_active += 1;
@@ -1204,22 +1190,10 @@ __global__ void __launch_bounds__(LT ? 1024 : (FOLD ? 512 : 256)) rx_sym_pack_ke
     auto sw_gather = [&](Sw& w) {
       if (PROF) { asm volatile("" ::"v"(w.c)); stamp(1); }  // phase 1: window byte, filter clear
       // current byte's slice of row s; 32-bit byte offset from a scalar base (table < 4 GiB) keeps the address
-      // arithmetic out of the 64-bit VALU path.  Accept states gather too (their rows are empty by definition).
-      w.x = 0u;
-      if (LT) {
-        // one LDS word: the state's only non-empty slice with its class in bits 27:20, or — for the pinned state — the word
-        // of class c of its full row, tagged the same way; x = the word if the tag is c, else nothing
-        const uint32_t* tw = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds) + (L::CMAPW << 2) +
-                                                               (w.s == p.pin_state ? ((p.size + 1u + w.c) << 2) : (w.s << 2)));
-        const uint32_t d = *tw;
-        const uint32_t t = d ^ (w.c << 20);
-        w.x = (t & RXLT_CLASS_MASK) ? 0u : t;
-        if (__builtin_expect(wballot((d >> 30) == 1u) != 0ull, 0)) {  // a state with edges on several classes: its row is in HBM only
-          if ((d >> 30) == 1u)
-            w.x = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(symidx) + ((__umul24(w.s, ncls_v) + w.c) << 2)) &
-                  ~(RXE_PIN | RXE_MAYDUP);
-        }
-      } else if (w.have) {  // s < 2^24, ncls <= 256: 24-bit multiply
+      // arithmetic out of the 64-bit VALU path.  Lanes without an entry sit out (the vector L1 looks every lane's address up,
+      // a lane that is masked off costs it nothing); accept states gather too — their rows are empty by definition.
+      w.x = x_none;
+      if (w.have) {  // s < 2^24, ncls <= 256: 24-bit multiply
         w.x = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(symidx) + ((__umul24(w.s, ncls_v) + w.c) << 2));
       }
     };
@@ -1251,7 +1225,10 @@ __global__ void __launch_bounds__(LT ? 1024 : (FOLD ? 512 : 256)) rx_sym_pack_ke
       if (!RX_AB_PREDICATE_IDLE || w.v0) w.o0 = atomicOr(fword(w.sreg, fnext_b, h0), w.v0);
       if (!RX_AB_PREDICATE_IDLE || w.v1) w.o1 = atomicOr(fword(w.sreg, fnext_b, h1), w.v1);
     };
-    auto sw_finish = [&](Sw& w) {
+    // (two parts: in an interleaved pair every fresh candidate of BOTH sweeps is in the list before either sweep's rare
+    // path runs — a duplicate check scans the list for candidates whose filter bit was already set, and that bit may have
+    // been set by the other sweep's atomic)
+    auto sw_append = [&](Sw& w) {
       if (PROF) { asm volatile("" ::"v"(w.o0), "v"(w.o1)); stamp(3); }  // phase 3: the two filter atomics
       // fresh: candidate whose bit was clear; maybe: candidate whose bit was already set
       // (v is one bit or nothing, d = the part of it that was already set: fresh <=> v != d, and d is needed below anyway)
@@ -1262,9 +1239,12 @@ __global__ void __launch_bounds__(LT ? 1024 : (FOLD ? 512 : 256)) rx_sym_pack_ke
         if (w.v1 != d1) nlist[rank_below_plus(mf1, Nn + (uint32_t)__popcll(mf0))] = w.t1;
       }
       Nn += (uint32_t)__popcll(mf0) + (uint32_t)__popcll(mf1);
+    };
+    auto sw_rare = [&](Sw& w) {
       // Everything that is rare — an accept state among the entries, a candidate whose filter bit was already set, a row
       // with several targets on the byte — hides behind ONE test (a v_cmp that writes a lane mask and the branch on it cost
       // as much as four plain VALU instructions each: tools/issue_bench).
+      const uint32_t d0 = w.v0 & w.o0, d1 = w.v1 & w.o1;
       const uint32_t dup_bits = d0 | d1;
       if (__builtin_expect(wballot(((w.e & RXE_ACCEPT) | (w.x & RXE_OVF) | dup_bits) != 0u) == 0ull, 1)) {
         stamp(4);
@@ -1369,8 +1349,10 @@ __global__ void __launch_bounds__(LT ? 1024 : (FOLD ? 512 : 256)) rx_sym_pack_ke
         sw_atom(A);
         sw_atom(B);
         __builtin_amdgcn_sched_barrier(0);  // all four atomics issued before the first result is looked at
-        sw_finish(A);
-        sw_finish(B);
+        sw_append(A);
+        sw_append(B);
+        sw_rare(A);
+        sw_rare(B);
         b0 += 128u;
         cp += 128;
       } else {
@@ -1380,7 +1362,8 @@ __global__ void __launch_bounds__(LT ? 1024 : (FOLD ? 512 : 256)) rx_sym_pack_ke
         fold_in_flight();
         sw_atom(A);
         __builtin_amdgcn_sched_barrier(0);  // keep the first result's consumers behind the second atomic's issue
-        sw_finish(A);
+        sw_append(A);
+        sw_rare(A);
         b0 += 64u;
         cp += 64;
       }
@@ -2286,24 +2269,6 @@ static int launch_pack_as(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t
   return launch_one(rx_sym_pack_kernel<S, false, false, false, false>, p, g, wpb * 64u, lds, s);
 }
 
-// LT builds: one copy of the state table per block, as many wavefronts beside it as the LDS holds (up to sixteen)
-template <int S>
-static int launch_ltab(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s, size_t lds_per_cu) {
-  using L = PackLayout<S, false, false, true>;
-  const uint32_t fixed = L::CMAPW + p.size + 1u + p.n_classes;
-  const uint32_t waves = (p.n_streams + S - 1) / S;
-  uint32_t wpb = 16;
-  while (wpb > 1 && (size_t)(fixed + wpb * L::WAVE_WORDS) * 4u > lds_per_cu) wpb--;
-  if ((size_t)(fixed + wpb * L::WAVE_WORDS) * 4u > lds_per_cu) return (int)hipErrorInvalidValue;
-  // (no point in a block larger than the batch needs on its busiest CU)
-  const uint32_t cus = cfg.cu_count > 0 ? (uint32_t)cfg.cu_count : 256u;
-  const uint32_t need = (waves + cus - 1) / cus;
-  if (need < wpb) wpb = need ? need : 1u;
-  const uint32_t grid = (waves + wpb - 1) / wpb;
-  const uint32_t lds = (fixed + wpb * L::WAVE_WORDS) * 4u;
-  return launch_one(rx_sym_pack_kernel<S, false, false, false, false, true>, p, grid ? grid : 1u, wpb * 64u, lds, s);
-}
-
 template <int S>
 static int launch_pack(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s) {
   if (cfg.prune && !cfg.stats && p.symidx_p) return launch_pack_as<S, true>(p, cfg, s);
@@ -2380,13 +2345,6 @@ int rx_launch(const RxParams& p, const RxLaunchCfg& cfg, void* hip_stream) {
         else if (gl <= 32) e = launch_fold<32>(p, cfg, s, lds_cu);
         else if (gl <= 48) e = launch_fold<48>(p, cfg, s, lds_cu);
         else e = launch_fold<64>(p, cfg, s, lds_cu);
-      } else if (cfg.kernel == RX_KERNEL_SYM_PACK && cfg.ltab && !cfg.stats && !cfg.prune && p.lt_tab) {
-        const size_t lds_cu = cfg.lds_per_cu ? cfg.lds_per_cu : 160u * 1024u;
-        const uint32_t gl = cfg.group_lanes;  // nearest instantiated number of streams per wavefront
-        if (gl <= 8) e = launch_ltab<8>(p, cfg, s, lds_cu);
-        else if (gl <= 13) e = launch_ltab<13>(p, cfg, s, lds_cu);
-        else if (gl <= 16) e = launch_ltab<16>(p, cfg, s, lds_cu);
-        else e = launch_ltab<24>(p, cfg, s, lds_cu);
       } else if (cfg.kernel == RX_KERNEL_SYM_PACK) {
         if (cfg.group_lanes == 2) e = launch_pack<2>(p, cfg, s);
         else if (cfg.group_lanes == 4) e = launch_pack<4>(p, cfg, s);

@@ -18,7 +18,7 @@ KERNEL_NAMES = {0: "auto", 1: "csr_wave", 2: "sym_wave", 3: "sym_group", 4: "sym
 
 # rx_opts.flags (A/B and diagnostic switches; read at plan creation, never from the environment)
 OPT_NO_PRUNE, OPT_FORCE_PRUNE, OPT_VERBOSE, OPT_PROFILE_PACK, OPT_NO_FOLD, OPT_FORCE_FOLD, OPT_REG_NO_SKIP = 1, 2, 4, 8, 16, 32, 64
-OPT_INJECT_RUN_FAULT, OPT_NO_PROBE, OPT_LDS_TABLE = 128, 256, 512
+OPT_INJECT_RUN_FAULT, OPT_NO_PROBE = 128, 256
 
 EVENT_DT = np.dtype([("stream", "<u4"), ("k", "<u4"), ("state", "<u4")])
 

@@ -32,11 +32,6 @@ def kernels(rx):
             dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=32, flags=rx.host.OPT_FORCE_FOLD),
             dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=48, flags=rx.host.OPT_FORCE_FOLD | rx.host.OPT_FORCE_PRUNE),
             dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=64, flags=rx.host.OPT_FORCE_FOLD),
-            # the state table in LDS (up to sixteen wavefronts per block share it); falls back to the plain build when the automaton does not qualify
-            dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=8, flags=rx.host.OPT_LDS_TABLE),
-            dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=13, flags=rx.host.OPT_LDS_TABLE),
-            dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=16, flags=rx.host.OPT_LDS_TABLE),
-            dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=24, flags=rx.host.OPT_LDS_TABLE),
             # register-resident one-wavefront-per-stream kernel, folded (default) and unfolded, with and without stepping over idle passes
             dict(kernel=rx.KERNEL_SYM_REG), dict(kernel=rx.KERNEL_SYM_REG, flags=rx.host.OPT_NO_FOLD),
             dict(kernel=rx.KERNEL_SYM_REG, flags=rx.host.OPT_REG_NO_SKIP), dict(kernel=rx.KERNEL_SYM_REG, flags=rx.host.OPT_REG_NO_SKIP | rx.host.OPT_NO_FOLD)]

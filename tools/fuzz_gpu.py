@@ -79,7 +79,7 @@ def one_case(rng, trial):
         stats = bool(rng.integers(2))  # the statistics build and the plain build are different kernels (pruning, marks)
         # batches here are too small for the probe that normally decides: force the pruned / folded builds half the time
         flags = (rx.host.OPT_FORCE_PRUNE if rng.integers(2) else 0) | (rx.host.OPT_FORCE_FOLD if rng.integers(2) else 0) | \
-            (rx.host.OPT_REG_NO_SKIP if rng.integers(2) else 0) | (rx.host.OPT_LDS_TABLE if rng.integers(3) == 0 else 0)
+            (rx.host.OPT_REG_NO_SKIP if rng.integers(2) else 0)
         got = rx.match(nfa, rows, mode=mode, want_match_count=True, collect_stats=stats, events_cap=CAP, flags=flags, **kern)
         ok = (got["n_events"] == ref["n_events"] and (overflow or np.array_equal(got["events"], ref["events"].astype(got["events"].dtype)))
               and np.array_equal(got["match_count"], ref["match_count"]) and np.array_equal(got["final_active"], ref["final_active"])
@@ -97,8 +97,7 @@ def one_case(rng, trial):
     if rng.integers(4) == 0:  # every fourth case also with the final sets as lists (one-shot form of rx_plan_run)
         cap = int(max(64, np.unpackbits(ref["final_active"].view(np.uint8)).sum() + 1))
         ckw = [dict(), dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=int(rng.choice([4, 8, 13, 16, 32]))),
-               dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=16, flags=rx.host.OPT_LDS_TABLE),
-               dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=16, flags=rx.host.OPT_FORCE_FOLD)][int(rng.integers(4))]
+               dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=16, flags=rx.host.OPT_FORCE_FOLD)][int(rng.integers(3))]
         got = rx.match(nfa, rows, mode=mode, events_cap=CAP, compact_final=cap, **ckw)
         if got["final_states_overflow"] or not np.array_equal(rx.host.expand_final(got, nfa.nw64), ref["final_active"]) or \
                 got["n_events"] != ref["n_events"]:
