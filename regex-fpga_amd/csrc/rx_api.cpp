@@ -767,9 +767,12 @@ static int auto_probe_pack(rx_plan* p) {
   double spilled = 0;
   int rc = run(16, true, false, &spilled);
   if (rc) return rc;
-  // (the pack kernel's own share of the active states: what streams that were handed off do afterwards, on the wave kernel,
-  // says nothing about how full the pack kernel's lists are — since round 3 only the stream that overflows leaves)
-  const double active = (double)(cnt[7] ? cnt[7] : cnt[1]) / units, spilled16 = spilled;
+  // (When only a few streams left the sample run, the pack kernel's own share of the active states is the better measure of
+  // how full its lists are: what a stream that was handed off does afterwards, on the wave kernel, says nothing about them —
+  // since round 3 only the stream that overflows leaves.  When most of the sample left, the own share is what was counted
+  // BEFORE they left and says nothing either: then the total stands.)
+  const double spilled16 = spilled;
+  const double active = (double)((spilled16 <= 0.05 && cnt[7]) ? cnt[7] : cnt[1]) / units;
   p->probe_active = active;
   // the pack kernel is fastest when one pass of a wavefront is ONE sweep with 30-37 of the 64 lanes busy:
   // streams per wavefront ~ 33 / (list entries per stream)   (snort_16: T 2.3 -> 13, U 1.15 -> 32)

@@ -860,7 +860,6 @@ template <int S, bool STATS, bool PROF, bool PRUNE, bool FOLD>
 __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxParams p) {
   static_assert(!((PRUNE || FOLD) && (STATS || PROF)), "statistics / stamped builds run unpruned and unfolded");
   constexpr bool LOOK = PRUNE || FOLD;  // the window carries one byte of look-ahead
-  constexpr bool PAIR = !PROF;          // lists longer than 64 entries: two sweeps interleaved (see the pass)
   constexpr uint32_t MARK = 1u << 29;  // STATS only: entry was inserted from a multi-target row
   unsigned long long t_prev = 0, t_sum[7] = {0, 0, 0, 0, 0, 0, 0};
   // PROF: shader clock this wave ran at = (s_memtime delta) / (s_memrealtime delta) x 100 MHz (MI355X_MICROARCH.md, DVFS item 6)
@@ -963,8 +962,9 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
   // A lane without an entry still runs the unpredicated LDS operations of a pass (zero stores into the filter being
   // wiped, OR 0 into the filter being filled): its pseudo entry points every lane at a different (slot, filter word)
   // so that those no-ops do not pile up on one LDS address.
-  const uint32_t x_none = (lane / (uint32_t)S) << 5;
-  const uint32_t e_none = 0x80000000u | ((lane % (uint32_t)S) << SID_SHIFT) | x_none;
+  // (Its state id is `size`: the row behind the last state's in the slice index, all zero — idle lanes gather like
+  // everybody else, no EXEC masking, and find nothing; so do accept states, whose rows are empty by definition.)
+  const uint32_t e_none = 0x80000000u | ((lane % (uint32_t)S) << SID_SHIFT) | p.size;
 
   unsigned long long busy = ~0ull;  // FOLD: bit j = pass j of the current window has an emission of the folded state (wave-uniform)
   // window refill at a pass k that is a multiple of 64: bytes -> byte classes on the way into LDS, next window requested
@@ -1130,44 +1130,37 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
     constexpr uint32_t E_NONE = 0x80000000u;  // list-entry flag of a lane without an entry (bit 31 is otherwise unused)
     const uint32_t Ns = (uint32_t)__builtin_amdgcn_readfirstlane((int)N);  // wave-uniform: keep the loop scalar
     if ((FOLD || PRUNE) && consume) fold_entries += Ns;  // (scalar) what AUTO's probe reads: list entries left per stream-byte
-    // One sweep = up to 64 list entries, one per lane, in five stages; every stage ends with memory operations in flight
-    // and the next one starts by waiting for them (list read | class byte, filter clear | slice gather | two filter atomics |
-    // ballots, appends, rare paths).  A pass whose list holds more than 64 entries runs TWO sweeps interleaved stage by
-    // stage (A's and B's reads, then A's and B's class bytes, ...): the dependent chain of a pass — which is what a pass
-    // costs as long as a SIMD has few wavefronts (profiles/r03_issue_ceiling) — is paid once for 128 entries.
-    struct Sw {
-      bool have;
-      uint32_t e, sid, s, c, cnx, x, e_keep, t1, v0, v1, o0, o1;
-      uint32_t* sreg;
-    };
-    constexpr uint32_t T1_MASK = RXE_TGT_MASK | RXE_ACCEPT;
-    auto sw_read = [&](Sw& w, const uint32_t* cp, uint32_t rem) {
-      w.have = lane < rem;  // (rem: scalar)
-      w.e = e_none;
-      if (w.have) w.e = *cp;
-    };
-    // accept pulses of the entries that are accept states (FPGA.v:210-226); a lane without an entry never has the flag
-    auto accept_pulses = [&](Sw& w) {
-      if (wballot(w.e & RXE_ACCEPT) != 0ull && !replay) {
-        const bool acc = (w.e & RXE_ACCEPT) != 0u;
-        uint32_t dummy = 0;
-        emit_events(p, acc, w.s, stream0 + w.sid, k, lane, dummy);
-        if (acc) atomicOr(&w.sreg[2u * L::FW + L::WINW], 1u << (k & 31u));
+    const uint32_t* cp = clist + lane;  // this lane's entry of the sweep (a carried address: no index arithmetic per sweep)
+    for (uint32_t b0 = 0; b0 < Ns; b0 += 64u, cp += 64) {
+      const bool have = lane < Ns - b0;  // (scalar subtraction, one v_cmp)
+      uint32_t e = *cp;  // lanes past N read harmless LDS words of this wave and are overwritten below
+      if (!have) e = e_none;
+      if (PROF) { asm volatile("" ::"v"(e)); stamp(0); }  // phase 0: refill check + list read
+      const uint32_t sid = (e >> SID_SHIFT) & SID_BITS;
+      const uint32_t s = e & RXE_TGT_MASK;
+      uint32_t* sreg = sreg0 + sid * L::STRIDE;
+      // accept pulses of the entries that are accept states (FPGA.v:210-226); a lane without an entry never has the flag
+      auto accept_pulses = [&]() {
+        if (wballot(e & RXE_ACCEPT) != 0ull && !replay) {
+          const bool acc = (e & RXE_ACCEPT) != 0u;
+          uint32_t dummy = 0;
+          emit_events(p, acc, s, stream0 + sid, k, lane, dummy);
+          if (acc) atomicOr(&sreg[2u * L::FW + L::WINW], 1u << (k & 31u));
+        }
+      };
+      if (!consume) {  // RX_MODE_FULL's last pass: nothing but the pulses
+        accept_pulses();
+        continue;
       }
-    };
-    auto sw_class = [&](Sw& w) {
-      if (PROF) { asm volatile("" ::"v"(w.e)); stamp(0); }  // phase 0: refill check + list read
-      w.sid = (w.e >> SID_SHIFT) & SID_BITS;
-      w.s = w.e & RXE_TGT_MASK;
-      w.sreg = sreg0 + w.sid * L::STRIDE;
-      w.c = reinterpret_cast<const uint8_t*>(w.sreg + 2u * L::FW)[kk];  // class of that stream's input_char
-      w.cnx = 0u;  // PRUNE: class of its NEXT byte (byte 64 of the window: the stash)
-      if (PRUNE) w.cnx = reinterpret_cast<const uint8_t*>(w.sreg + 2u * L::FW)[kk + 1u];
+      const bool live = (e & (E_NONE | RXE_ACCEPT)) == 0u;  // a real entry that is not an accept state: it has a row (statistics only)
+      const uint32_t c = reinterpret_cast<const uint8_t*>(sreg + 2u * L::FW)[kk];  // class of that stream's input_char
+      uint32_t cnx = 0u;  // PRUNE: class of its NEXT byte (byte 64 of the window: the stash)
+      if (PRUNE) cnx = reinterpret_cast<const uint8_t*>(sreg + 2u * L::FW)[kk + 1u];
       // zero the filter word this entry went through (lanes without an entry hit some word of the CURRENT filter of
       // a valid slot; that filter is being wiped this pass anyway and is not read before the next swap)
-      if (!RX_AB_PREDICATE_IDLE || w.have) *fword(w.sreg, fcur_b, w.s & HMASK) = 0u;
-      if (STATS && !replay && (w.e & E_NONE) == 0u) {
-        const uint32_t deg = rp[w.s + 1] - rp[w.s];
+      if (!RX_AB_PREDICATE_IDLE || have) *fword(sreg, fcur_b, s & HMASK) = 0u;
+      if (STATS && !replay && (e & E_NONE) == 0u) {
+        const uint32_t deg = rp[s + 1] - rp[s];
         st_active += 1;
         st_edges += deg;
         if (p.pair_cycles) {
@@ -1175,93 +1168,83 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
           // stream costs its clocks once.  Streams 2q / 2q+1 of the batch are such a pair; the odd
           // stream skips states the even stream also holds.  cost(i) per SURVEY.md §3.2.
           bool dup = false;
-          if (w.sid & 1u) {
-            const uint32_t key = (w.e ^ (1u << SID_SHIFT)) & KEY_MASK;
+          if (sid & 1u) {
+            const uint32_t key = (e ^ (1u << SID_SHIFT)) & KEY_MASK;
             for (uint32_t q = 0; q < N; q++) dup |= (clist[q] & KEY_MASK) == key;
           }
           if (!dup) {
-            const uint32_t a = p.size + 1u + rp[w.s];
+            const uint32_t a = p.size + 1u + rp[s];
             const uint32_t nlines = ((a + deg - 1u) >> 2) - (a >> 2) + 1u;
-            st_cost += 3u + ((w.s & 3u) == 3u ? 1u : 0u) + (deg == 0 ? 1u : nlines + 2u) + 1u - 1u;
+            st_cost += 3u + ((s & 3u) == 3u ? 1u : 0u) + (deg == 0 ? 1u : nlines + 2u) + 1u - 1u;
           }
         }
       }
-    };
-    auto sw_gather = [&](Sw& w) {
-      if (PROF) { asm volatile("" ::"v"(w.c)); stamp(1); }  // phase 1: window byte, filter clear
+      if (PROF) { asm volatile("" ::"v"(c)); stamp(1); }  // phase 1: accept check, window byte, filter clear
       // current byte's slice of row s; 32-bit byte offset from a scalar base (table < 4 GiB) keeps the address
-      // arithmetic out of the 64-bit VALU path.  Lanes without an entry sit out (the vector L1 looks every lane's address up,
-      // a lane that is masked off costs it nothing); accept states gather too — their rows are empty by definition.
-      w.x = x_none;
-      if (w.have) {  // s < 2^24, ncls <= 256: 24-bit multiply
-        w.x = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(symidx) + ((__umul24(w.s, ncls_v) + w.c) << 2));
-      }
-    };
-    auto sw_atom = [&](Sw& w) {
-      if (PROF) { asm volatile("" ::"v"(w.x)); stamp(2); }  // phase 2: slice gather
+      // arithmetic out of the 64-bit VALU path
+      // s < 2^24, ncls <= 256: 24-bit multiply; every lane gathers (accept states and idle lanes read empty rows)
+      const uint32_t x = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(symidx) + ((__umul24(s, ncls_v) + c) << 2));
       if (STATS && !replay) {
-        const bool live = (w.e & (E_NONE | RXE_ACCEPT)) == 0u;  // a real entry that is not an accept state: it has a row
-        if (w.x & RXE_OVF) st_ovf += 1;
-        if ((w.e & MARK) && live && w.x == 0u) st_dead += 1;  // came out of a multi-target row and dies at once
+        if (x & RXE_OVF) st_ovf += 1;
+        if ((e & MARK) && live && x == 0u) st_dead += 1;  // came out of a multi-target row and dies at once
       }
-      w.e_keep = STATS ? w.e & ~MARK : w.e;
+      const uint32_t e_keep = STATS ? e & ~MARK : e;
+      if (FOLD && !pin_done) {  // the gather is in flight: insert what the folded state emits meanwhile
+        __builtin_amdgcn_sched_barrier(0);
+        pin_stage();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (PROF) { asm volatile("" ::"v"(x)); stamp(2); }  // phase 2: slice gather
       // two candidates per lane: the state itself (self-loop) and the inline target.  Both filter atomics are issued
       // by every lane, back to back, with one wait: a lane without a candidate ORs 0 (a no-op) into the word its
       // hash names anyway instead of sitting out in a branch or selecting another address.
-      w.t1 = PRUNE ? (w.x & (xtmask | RXE_ACCEPT)) | (w.e_keep & ~T1_MASK)
-                   : (w.x & T1_MASK) | (w.e_keep & ~T1_MASK);  // v_bfi: a live e has only its slot bits outside the mask
-      const uint32_t h0 = w.e & HMASK, h1 = w.x & HMASK;
+      constexpr uint32_t T1_MASK = RXE_TGT_MASK | RXE_ACCEPT;
+      const uint32_t t1 = PRUNE ? (x & (xtmask | RXE_ACCEPT)) | (e_keep & ~T1_MASK)
+                                : (x & T1_MASK) | (e_keep & ~T1_MASK);  // v_bfi: a live e has only its slot bits outside the mask
+      const uint32_t h0 = e & HMASK, h1 = x & HMASK;
       // bit to set, 0 = no candidate: flag bit shifted down to 0/1, then up by the hash (two plain shifts; a select on the
       // flag would go through v_bfe_i32 + v_and, and three-operand VALU forms issue at half rate — DESIGN.md 3.4)
-      w.v0 = ((w.x >> 29) & 1u) << (h0 & 31u);
+      const uint32_t v0 = ((x >> 29) & 1u) << (h0 & 31u);
       static_assert(RXE_SELF == (1u << 29) && RXE_INLINE == (1u << 31), "flag positions used as shift counts");
       // (FOLD: a target that IS the folded state is dropped — the stream holds it anyway)
       // (PRUNE, narrow index: an inline target that is no accept state and has no edge on the stream's next byte can neither
       // pulse nor produce a successor: it is not inserted — except at the stream's last byte, whose sets are reported)
-      bool inl = FOLD ? (w.x & (RXE_INLINE | RXE_PIN)) == RXE_INLINE : (w.x & RXE_INLINE) != 0u;
-      if (PRUNE) inl = inl && (((w.x | keep_all) >> (16u + (w.cnx & 7u))) & 1u) != 0u;
-      w.v1 = (!PRUNE && !FOLD) ? (w.x >> 31) << (h1 & 31u) : (inl ? 1u << (h1 & 31u) : 0u);
-      w.o0 = w.o1 = 0u;
-      if (!RX_AB_PREDICATE_IDLE || w.v0) w.o0 = atomicOr(fword(w.sreg, fnext_b, h0), w.v0);
-      if (!RX_AB_PREDICATE_IDLE || w.v1) w.o1 = atomicOr(fword(w.sreg, fnext_b, h1), w.v1);
-    };
-    // (two parts: in an interleaved pair every fresh candidate of BOTH sweeps is in the list before either sweep's rare
-    // path runs — a duplicate check scans the list for candidates whose filter bit was already set, and that bit may have
-    // been set by the other sweep's atomic)
-    auto sw_append = [&](Sw& w) {
-      if (PROF) { asm volatile("" ::"v"(w.o0), "v"(w.o1)); stamp(3); }  // phase 3: the two filter atomics
+      bool inl = FOLD ? (x & (RXE_INLINE | RXE_PIN)) == RXE_INLINE : (x & RXE_INLINE) != 0u;
+      if (PRUNE) inl = inl && (((x | keep_all) >> (16u + (cnx & 7u))) & 1u) != 0u;
+      const uint32_t v1 = (!PRUNE && !FOLD) ? (x >> 31) << (h1 & 31u) : (inl ? 1u << (h1 & 31u) : 0u);
+      uint32_t o0 = 0u, o1 = 0u;
+      if (!RX_AB_PREDICATE_IDLE || v0) o0 = atomicOr(fword(sreg, fnext_b, h0), v0);
+      if (!RX_AB_PREDICATE_IDLE || v1) o1 = atomicOr(fword(sreg, fnext_b, h1), v1);
+      __builtin_amdgcn_sched_barrier(0);  // keep the first result's consumers behind the second atomic's issue
+      if (PROF) { asm volatile("" ::"v"(o0), "v"(o1)); stamp(3); }  // phase 3: the two filter atomics
       // fresh: candidate whose bit was clear; maybe: candidate whose bit was already set
       // (v is one bit or nothing, d = the part of it that was already set: fresh <=> v != d, and d is needed below anyway)
-      const uint32_t d0 = w.v0 & w.o0, d1 = w.v1 & w.o1;
-      const uint64_t mf0 = wballot(w.v0 != d0), mf1 = wballot(w.v1 != d1);
+      const uint32_t d0 = v0 & o0, d1 = v1 & o1;
+      const uint64_t mf0 = wballot(v0 != d0), mf1 = wballot(v1 != d1);
       if (__builtin_expect(Nn <= L::CAPW, 1)) {  // (wave-uniform) past that the pass ends in a hand-off anyway; keeps writes inside LISTW
-        if (w.v0 != d0) nlist[rank_below_plus(mf0, Nn)] = w.e_keep;
-        if (w.v1 != d1) nlist[rank_below_plus(mf1, Nn + (uint32_t)__popcll(mf0))] = w.t1;
+        if (v0 != d0) nlist[rank_below_plus(mf0, Nn)] = e_keep;
+        if (v1 != d1) nlist[rank_below_plus(mf1, Nn + (uint32_t)__popcll(mf0))] = t1;
       }
       Nn += (uint32_t)__popcll(mf0) + (uint32_t)__popcll(mf1);
-    };
-    auto sw_rare = [&](Sw& w) {
       // Everything that is rare — an accept state among the entries, a candidate whose filter bit was already set, a row
       // with several targets on the byte — hides behind ONE test (a v_cmp that writes a lane mask and the branch on it cost
       // as much as four plain VALU instructions each: tools/issue_bench).
-      const uint32_t d0 = w.v0 & w.o0, d1 = w.v1 & w.o1;
+      // (PRUNE builds serve automata that meet multi-target rows in nearly every sweep: there the pre-test is one ballot too many)
       const uint32_t dup_bits = d0 | d1;
-      if (__builtin_expect(wballot(((w.e & RXE_ACCEPT) | (w.x & RXE_OVF) | dup_bits) != 0u) == 0ull, 1)) {
+      if (!PRUNE && __builtin_expect(wballot(((e & RXE_ACCEPT) | (x & RXE_OVF) | dup_bits) != 0u) == 0ull, 1)) {
         stamp(4);
-        return;
+        continue;
       }
-      accept_pulses(w);
+      accept_pulses();
       if (wballot(dup_bits != 0u) != 0ull) {
         wave_sync();
-        resolve(d0 != 0u, w.e_keep);
-        resolve(d1 != 0u, w.t1);
+        resolve(d0 != 0u, e_keep);
+        resolve(d1 != 0u, t1);
       }
       stamp(4);  // phase 4: ballots, slots, list writes, rare duplicate resolution
       // rows with several targets on this byte (rare on snort_16, every pass on l7 and on compiled rule sets):
       // the target lists of as many such entries as fit are laid side by side over the 64 lanes (a scalar walk
       // hands every entry its lane range), then ONE sweep loads and inserts them all
-      const uint32_t x = w.x, sid = w.sid;
-      uint32_t* sreg = w.sreg;
       uint64_t mo = wballot(x & RXE_OVF);
       if (__builtin_expect(mo != 0, 0)) {
         uint32_t myoff = x & RXE_TGT_MASK, mycnt = 0u;  // this lane's list: ovf[myoff] = count, targets behind it
@@ -1288,8 +1271,8 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
         uint32_t total = 0, my_at = 0, my_sid = 0;
         auto flush = [&]() {
           const bool act = lane < total;
-          const uint32_t ww = act ? ovf[my_at] : 0u;
-          insert(act && !(FOLD && (ww & RXE_PIN)), (ww & (RXE_TGT_MASK | RXE_ACCEPT)) | (my_sid << SID_SHIFT) | (STATS ? MARK : 0u), sreg0 + my_sid * L::STRIDE);
+          const uint32_t w = act ? ovf[my_at] : 0u;
+          insert(act && !(FOLD && (w & RXE_PIN)), (w & (RXE_TGT_MASK | RXE_ACCEPT)) | (my_sid << SID_SHIFT) | (STATS ? MARK : 0u), sreg0 + my_sid * L::STRIDE);
           total = 0;
         };
         while (mo) {
@@ -1303,8 +1286,8 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
             uint32_t* oreg = sreg0 + osid * L::STRIDE;
             for (uint32_t q0 = 0; q0 < cnt; q0 += 64u) {
               const bool act = q0 + lane < cnt;
-              const uint32_t ww = act ? ovf[off + 1u + q0 + lane] : 0u;
-              insert(act && !(FOLD && (ww & RXE_PIN)), (ww & (RXE_TGT_MASK | RXE_ACCEPT)) | (osid << SID_SHIFT) | (STATS ? MARK : 0u), oreg);
+              const uint32_t w = act ? ovf[off + 1u + q0 + lane] : 0u;
+              insert(act && !(FOLD && (w & RXE_PIN)), (w & (RXE_TGT_MASK | RXE_ACCEPT)) | (osid << SID_SHIFT) | (STATS ? MARK : 0u), oreg);
             }
           } else {
             const uint32_t d = lane - total;  // lanes [total, total+cnt) take this entry's targets
@@ -1313,59 +1296,6 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
           }
         }
         if (total != 0) flush();
-      }
-    };
-    auto fold_in_flight = [&]() {
-      if (FOLD && !pin_done) {  // the gathers are in flight: insert what the folded state emits meanwhile
-        __builtin_amdgcn_sched_barrier(0);
-        pin_stage();
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-
-    const uint32_t* cp = clist + lane;  // this lane's entry of the sweep (a carried address: no index arithmetic per sweep)
-    for (uint32_t b0 = 0; b0 < Ns;) {
-      const uint32_t rem = Ns - b0;
-      Sw A;
-      if (!consume) {  // RX_MODE_FULL's last pass: nothing but the pulses
-        sw_read(A, cp, rem);
-        A.sid = (A.e >> SID_SHIFT) & SID_BITS;
-        A.s = A.e & RXE_TGT_MASK;
-        A.sreg = sreg0 + A.sid * L::STRIDE;
-        accept_pulses(A);
-        b0 += 64u;
-        cp += 64;
-        continue;
-      }
-      if (PAIR && rem > 64u) {  // (wave-uniform)
-        Sw B;
-        sw_read(A, cp, rem);
-        sw_read(B, cp + 64, rem - 64u);
-        sw_class(A);
-        sw_class(B);
-        sw_gather(A);
-        sw_gather(B);
-        fold_in_flight();
-        sw_atom(A);
-        sw_atom(B);
-        __builtin_amdgcn_sched_barrier(0);  // all four atomics issued before the first result is looked at
-        sw_append(A);
-        sw_append(B);
-        sw_rare(A);
-        sw_rare(B);
-        b0 += 128u;
-        cp += 128;
-      } else {
-        sw_read(A, cp, rem);
-        sw_class(A);
-        sw_gather(A);
-        fold_in_flight();
-        sw_atom(A);
-        __builtin_amdgcn_sched_barrier(0);  // keep the first result's consumers behind the second atomic's issue
-        sw_append(A);
-        sw_rare(A);
-        b0 += 64u;
-        cp += 64;
       }
     }
 

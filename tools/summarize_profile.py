@@ -45,12 +45,16 @@ def main():
     print(short, "avg", out["kernel_trace_avg_ns"] / 1e6, "ms;", {k: round(v["mean_per_launch"]) for k, v in c.items()})
     # figures bench.py copies into roofline.pmc (only while the kernel source is the one that was profiled)
     t_s = out["kernel_trace_avg_ns"] * 1e-9
-    n_simd, clk = 1024, 2.4e9
+    # shader clock under this load, measured in the kernel (s_memtime / s_memrealtime): 2.37 GHz.  (SQ_WAVE_CYCLES
+    # undercounts by ~23 %: do not derive the clock from it.)
+    n_simd, clk = 1024, 2.37e9
     pmc = {}
     if "SQ_INSTS_VALU" in c:
-        pmc["valu_issue_frac"] = round(c["SQ_INSTS_VALU"]["mean_per_launch"] / (n_simd * clk * t_s / 2.0), 4)
+        # lower bound: 2.1 cycles per plain VALU instruction; forms with an SGPR operand / result or three sources take 4
+        pmc["valu_issue_frac"] = round(c["SQ_INSTS_VALU"]["mean_per_launch"] * 2.1 / (n_simd * clk * t_s), 4)
     if "SQ_INSTS_SALU" in c:
-        pmc["salu_issue_frac"] = round(c["SQ_INSTS_SALU"]["mean_per_launch"] / (256 * clk * t_s), 4)
+        # one SALU instruction per 4 cycles per SIMD (tools/issue_bench); branches are not in SQ_INSTS_SALU
+        pmc["salu_issue_frac"] = round(c["SQ_INSTS_SALU"]["mean_per_launch"] * 4.0 / (n_simd * clk * t_s), 4)
     if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
         pmc["wave_cycles_waiting_frac"] = round(c["SQ_WAIT_ANY"]["mean_per_launch"] / c["SQ_WAVE_CYCLES"]["mean_per_launch"], 4)
     # (SQ_LDS_BANK_CONFLICT and SQ_LDS_IDX_ACTIVE count LDS-array cycles; SQ_ACTIVE_INST_LDS counts quad-cycles of waves
