@@ -75,6 +75,17 @@ __device__ __forceinline__ uint32_t bcast(uint32_t v, uint32_t src_lane) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src_lane);
 }
 
+// Kernel arguments for COLD code (hand-offs, the final sets at the end of a kernel): read from the kernel-argument segment at
+// the place of use instead of being kept in SGPRs across the pass loop, where they would push hot values into lane spills
+// (the pack kernel sits at 100 of 102 SGPRs).  The address goes through an empty asm so that the loads are not merged with
+// the hoisted ones.  The kernels take their RxParams by value as the first argument: offset 0 of the segment.
+typedef const RxParams __attribute__((address_space(4))) * RxColdParams;
+__device__ __forceinline__ RxColdParams cold_params() {
+  unsigned long long a = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(a));
+  return (RxColdParams)a;
+}
+
 // ---- launch prologue: what used to be host-side resets between two launches ------------------------
 // Block 0 zeroes the counter set of the NEXT launch (RxParams::zero_next); nothing in this launch touches that set.
 __device__ __forceinline__ void zero_next_counters(const RxParams& p) {
@@ -1307,6 +1318,7 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
         // the next list that was written — with its S_k (its entries of the current list, still intact) and k, to be
         // finished by the wave kernel; its slot goes idle.  The other streams run this pass again (replay: their accept
         // pulses of pass k are out already, as are the leaving stream's, which the wave kernel therefore skips at k).
+        const RxColdParams cq = cold_params();
         wave_sync();
         uint32_t c_next = 0;
         {
@@ -1322,15 +1334,15 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
         // loop conditions — stays scalar for the compiler too)
         const uint32_t v = 63u - ((uint32_t)__builtin_amdgcn_readfirstlane((int)key) & 63u);
         unsigned long long b = 0;
-        if (lane == 0) b = atomicAdd(p.spill_count, 1ull);
+        if (lane == 0) b = atomicAdd(cq->spill_count, 1ull);
         const uint32_t slot = bcast((uint32_t)b, 0);
-        uint32_t* row = p.spill_rows + (size_t)slot * p.nw64x2;
-        for (uint32_t w = lane; w < p.nw64x2; w += 64u) row[w] = 0u;
+        uint32_t* row = cq->spill_rows + (size_t)slot * cq->nw64x2;
+        for (uint32_t w = lane; w < cq->nw64x2; w += 64u) row[w] = 0u;
         if (lane == v) {
-          p.spill_streams[slot] = stream0 + v;
-          p.spill_k[slot] = k;
-          if (p.anymatch)
-            p.anymatch[(size_t)(stream0 + v) * p.anymatch_stride + (k >> 5)] = sreg0[v * L::STRIDE + 2u * L::FW + L::WINW];
+          cq->spill_streams[slot] = stream0 + v;
+          cq->spill_k[slot] = k;
+          if (cq->anymatch)
+            cq->anymatch[(size_t)(stream0 + v) * cq->anymatch_stride + (k >> 5)] = sreg0[v * L::STRIDE + 2u * L::FW + L::WINW];
         }
         __threadfence();
         wave_sync();
@@ -1349,7 +1361,7 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
           if (keep) nlist[rank_below_plus(mk, M)] = e;
           M += (uint32_t)__popcll(mk);
         }
-        if (FOLD && k >= 1u && lane == 0) atomicOr(&row[p.pin_state >> 5], 1u << (p.pin_state & 31u));  // S_k holds the folded state
+        if (FOLD && k >= 1u && lane == 0) atomicOr(&row[cq->pin_state >> 5], 1u << (cq->pin_state & 31u));  // S_k holds the folded state
         {
           uint32_t* t = clist; clist = nlist; nlist = t;
         }
@@ -1415,7 +1427,8 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
   // Final active sets of the streams that stayed (FPGA.v:733-737: the set that survives the last byte).  The next-list
   // buffer is dead now and serves as scratch.
   const bool pin_in = FOLD && n_consume >= 1u;  // the folded state is in every set after the first byte
-  if (p.fin_states && !spilled) {
+  const RxColdParams cq = cold_params();
+  if (cq->fin_states && !spilled) {
     // As compact lists, straight from the list entries — no bitmask row is ever built.  Per entry its rank among its
     // stream's entries (ascending state), per stream (owner lane) the count and, FOLD, where the folded state goes; one
     // atomic per wavefront for the space.
@@ -1424,9 +1437,9 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
     for (uint32_t q = 0; q < N; q++) {
       const uint32_t eq = clist[q];
       const uint32_t sq = eq & RXE_TGT_MASK;
-      if (((eq >> SID_SHIFT) & SID_BITS) == lane && !(pin_in && sq == p.pin_state)) {
+      if (((eq >> SID_SHIFT) & SID_BITS) == lane && !(pin_in && sq == cq->pin_state)) {
         my_cnt++;
-        if (pin_in && sq < p.pin_state) pin_rank++;
+        if (pin_in && sq < cq->pin_state) pin_rank++;
       }
     }
     if (!owner) my_cnt = 0;
@@ -1438,14 +1451,14 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
     }
     const uint32_t total = bcast(incl, 63);
     unsigned long long base = 0;
-    if (lane == 0 && total) base = atomicAdd(p.fin_count, (unsigned long long)total);
+    if (lane == 0 && total) base = atomicAdd(cq->fin_count, (unsigned long long)total);
     base = ((unsigned long long)bcast((uint32_t)(base >> 32), 0) << 32) | bcast((uint32_t)base, 0);
     const unsigned long long my_off64 = base + (incl - my_cnt);
-    const uint32_t my_off = (uint32_t)(my_off64 < p.fin_cap ? my_off64 : p.fin_cap);
+    const uint32_t my_off = (uint32_t)(my_off64 < cq->fin_cap ? my_off64 : cq->fin_cap);
     if (owner) {
-      p.fin_off[stream0 + lane] = my_off;
-      p.fin_cnt[stream0 + lane] = my_cnt;
-      if (pin_in && my_off + pin_rank < p.fin_cap) p.fin_states[my_off + pin_rank] = p.pin_state;
+      cq->fin_off[stream0 + lane] = my_off;
+      cq->fin_cnt[stream0 + lane] = my_cnt;
+      if (pin_in && my_off + pin_rank < cq->fin_cap) cq->fin_states[my_off + pin_rank] = cq->pin_state;
     }
     if (lane < (uint32_t)S) slotw[lane] = my_off;
     wave_sync();
@@ -1453,25 +1466,25 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
       const uint32_t li = b0 + lane;
       const uint32_t e = li < N ? clist[li] : 0u;
       const uint32_t sid = (e >> SID_SHIFT) & SID_BITS, sq = e & RXE_TGT_MASK;
-      const bool valid = li < N && !(pin_in && sq == p.pin_state);
-      uint32_t rank = (pin_in && sq > p.pin_state) ? 1u : 0u;
+      const bool valid = li < N && !(pin_in && sq == cq->pin_state);
+      uint32_t rank = (pin_in && sq > cq->pin_state) ? 1u : 0u;
       for (uint32_t q = 0; q < N; q++) {
         const uint32_t eq = clist[q];
         rank += (((eq >> SID_SHIFT) & SID_BITS) == sid && (eq & RXE_TGT_MASK) < sq) ? 1u : 0u;
       }
       if (valid) {
         const uint32_t o = slotw[sid] + rank;
-        if (o < p.fin_cap) p.fin_states[o] = sq;
+        if (o < cq->fin_cap) cq->fin_states[o] = sq;
       }
     }
-  } else if (p.final_active && !spilled) {
+  } else if (cq->final_active && !spilled) {
     // As bitmask rows: each row is built in LDS (in slices of the scratch buffer's size for automata whose row is longer)
     // and stored ONCE with 8-byte stores — no zeroing in the prologue, no global atomics.
     constexpr uint32_t SLICE = L::LISTW & ~1u;
     for (uint32_t sl = 0; sl < n_mine; sl++) {
       if (((alive >> sl) & 1ull) == 0ull) continue;  // (wave-uniform) finished by the wave kernel
-      for (uint32_t w0 = 0; w0 < p.nw64x2; w0 += SLICE) {
-        const uint32_t nwords = p.nw64x2 - w0 < SLICE ? p.nw64x2 - w0 : SLICE;
+      for (uint32_t w0 = 0; w0 < cq->nw64x2; w0 += SLICE) {
+        const uint32_t nwords = cq->nw64x2 - w0 < SLICE ? cq->nw64x2 - w0 : SLICE;
         wave_sync();
         for (uint32_t w = lane; w < nwords; w += 64u) nlist[w] = 0u;
         wave_sync();
@@ -1481,11 +1494,11 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
           if (((e >> SID_SHIFT) & SID_BITS) == sl && wd >= w0 && wd - w0 < nwords) atomicOr(&nlist[wd - w0], 1u << (e & 31u));
         }
         if (pin_in && lane == 0) {
-          const uint32_t wd = p.pin_state >> 5;
-          if (wd >= w0 && wd - w0 < nwords) atomicOr(&nlist[wd - w0], 1u << (p.pin_state & 31u));
+          const uint32_t wd = cq->pin_state >> 5;
+          if (wd >= w0 && wd - w0 < nwords) atomicOr(&nlist[wd - w0], 1u << (cq->pin_state & 31u));
         }
         wave_sync();
-        uint2* row8 = reinterpret_cast<uint2*>(p.final_active + (size_t)(stream0 + sl) * p.nw64x2 + w0);
+        uint2* row8 = reinterpret_cast<uint2*>(cq->final_active + (size_t)(stream0 + sl) * cq->nw64x2 + w0);
         for (uint32_t w = lane; w < nwords / 2u; w += 64u) row8[w] = make_uint2(nlist[2u * w], nlist[2u * w + 1u]);
       }
     }
