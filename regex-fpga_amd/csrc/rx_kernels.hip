@@ -1314,61 +1314,77 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
     stamp(5);  // phase 5: overflow lists + loop control
     if (consume) {
       if (__builtin_expect(Nn > L::CAPW, 0)) {
-        // The wave-wide list cannot hold the next sets.  ONE stream leaves — the one with the most entries in the part of
-        // the next list that was written — with its S_k (its entries of the current list, still intact) and k, to be
-        // finished by the wave kernel; its slot goes idle.  The other streams run this pass again (replay: their accept
-        // pulses of pass k are out already, as are the leaving stream's, which the wave kernel therefore skips at k).
+        // The wave-wide list cannot hold the next sets.  The streams with the most entries in the part of the next list that
+        // was written leave — one if that brings the written part under 5/8 of the capacity (a single stream that explodes),
+        // more if the load is spread (then one at a time would overflow again a few passes on) — each with its S_k (its
+        // entries of the current list, still intact) and k, to be finished by the wave kernel; their slots go idle.  The other
+        // streams run this pass again (replay: their accept pulses of pass k are out already, as are the leaving streams',
+        // which the wave kernel therefore skips at k).
         const RxColdParams cq = cold_params();
         wave_sync();
         uint32_t c_next = 0;
-        {
-          const uint32_t lim = Nn < L::CAPW ? Nn : L::CAPW;
-          for (uint32_t q = 0; q < lim; q++) c_next += ((nlist[q] >> SID_SHIFT) & SID_BITS) == lane ? 1u : 0u;
-        }
-        uint32_t key = owner ? ((c_next + 1u) << 6) | (63u - lane) : 0u;  // most entries, lowest slot on ties; > 0 for every live slot
-        for (int d = 32; d >= 1; d >>= 1) {
-          const uint32_t o = (uint32_t)__shfl_xor((int)key, d);
-          key = o > key ? o : key;
-        }
-        // (every lane holds the maximum; through an SGPR so that everything derived from it — the set of live slots, the
-        // loop conditions — stays scalar for the compiler too)
-        const uint32_t v = 63u - ((uint32_t)__builtin_amdgcn_readfirstlane((int)key) & 63u);
+        const uint32_t lim = Nn < L::CAPW ? Nn : L::CAPW;
+        for (uint32_t q = 0; q < lim; q++) c_next += ((nlist[q] >> SID_SHIFT) & SID_BITS) == lane ? 1u : 0u;
+        unsigned long long victims = 0ull;  // (scalar)
+        uint32_t left = lim;
+        do {
+          // most entries, lowest slot on ties; > 0 for every live slot that has not been picked yet
+          uint32_t key = (owner && ((victims >> lane) & 1ull) == 0ull) ? ((c_next + 1u) << 6) | (63u - lane) : 0u;
+          for (int d = 32; d >= 1; d >>= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)key, d);
+            key = o > key ? o : key;
+          }
+          // (every lane holds the maximum; through an SGPR so that everything derived from it — the set of live slots, the
+          // loop conditions — stays scalar for the compiler too)
+          const uint32_t best = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+          if (best == 0u) break;
+          victims |= 1ull << (63u - (best & 63u));
+          left -= (best >> 6) - 1u;
+        } while (left > (L::CAPW * 5u) / 8u);
+        const uint32_t n_vict = (uint32_t)__popcll(victims);
         unsigned long long b = 0;
-        if (lane == 0) b = atomicAdd(cq->spill_count, 1ull);
-        const uint32_t slot = bcast((uint32_t)b, 0);
-        uint32_t* row = cq->spill_rows + (size_t)slot * cq->nw64x2;
-        for (uint32_t w = lane; w < cq->nw64x2; w += 64u) row[w] = 0u;
-        if (lane == v) {
-          cq->spill_streams[slot] = stream0 + v;
-          cq->spill_k[slot] = k;
+        if (lane == 0) b = atomicAdd(cq->spill_count, (unsigned long long)n_vict);
+        const uint32_t slot_base = bcast((uint32_t)b, 0);
+        const bool i_leave = ((victims >> lane) & 1ull) != 0ull;  // (lane == stream slot)
+        const uint32_t my_slot = slot_base + (uint32_t)__popcll(victims & ((1ull << lane) - 1ull));
+        if (lane < (uint32_t)S) slotw[lane] = my_slot;
+        {
+          uint32_t* rows = cq->spill_rows + (size_t)slot_base * cq->nw64x2;
+          for (uint32_t w = lane; w < n_vict * cq->nw64x2; w += 64u) rows[w] = 0u;
+        }
+        if (i_leave) {
+          cq->spill_streams[my_slot] = stream0 + lane;
+          cq->spill_k[my_slot] = k;
           if (cq->anymatch)
-            cq->anymatch[(size_t)(stream0 + v) * cq->anymatch_stride + (k >> 5)] = sreg0[v * L::STRIDE + 2u * L::FW + L::WINW];
+            cq->anymatch[(size_t)(stream0 + lane) * cq->anymatch_stride + (k >> 5)] = sreg0[lane * L::STRIDE + 2u * L::FW + L::WINW];
         }
         __threadfence();
         wave_sync();
-        // S_k of the leaving stream into its hand-off row; the list without it into the other buffer
+        // S_k of the leaving streams into their hand-off rows; the list without them into the other buffer
         uint32_t M = 0;
         for (uint32_t b0 = 0; b0 < N; b0 += 64u) {
           const uint32_t li = b0 + lane;
           const uint32_t e = li < N ? clist[li] : 0u;
-          const bool mine_v = li < N && ((e >> SID_SHIFT) & SID_BITS) == v;
-          if (mine_v) {
+          const uint32_t es = (e >> SID_SHIFT) & SID_BITS;
+          const bool goes = li < N && ((victims >> es) & 1ull) != 0ull;
+          if (goes) {
             const uint32_t sq = e & RXE_TGT_MASK;
-            atomicOr(&row[sq >> 5], 1u << (sq & 31u));
+            atomicOr(&cq->spill_rows[(size_t)slotw[es] * cq->nw64x2 + (sq >> 5)], 1u << (sq & 31u));
           }
-          const bool keep = li < N && !mine_v;
+          const bool keep = li < N && !goes;
           const uint64_t mk = wballot(keep);
           if (keep) nlist[rank_below_plus(mk, M)] = e;
           M += (uint32_t)__popcll(mk);
         }
-        if (FOLD && k >= 1u && lane == 0) atomicOr(&row[cq->pin_state >> 5], 1u << (cq->pin_state & 31u));  // S_k holds the folded state
+        if (FOLD && k >= 1u && i_leave)  // S_k holds the folded state
+          atomicOr(&cq->spill_rows[(size_t)my_slot * cq->nw64x2 + (cq->pin_state >> 5)], 1u << (cq->pin_state & 31u));
         {
           uint32_t* t = clist; clist = nlist; nlist = t;
         }
         N = M;
         // both filters of every slot start clean (bits of entries that were counted but not written would otherwise stay)
         for (uint32_t w = lane; w < (uint32_t)S * 2u * L::FW; w += 64u) sreg0[(w / (2u * L::FW)) * L::STRIDE + (w % (2u * L::FW))] = 0u;
-        alive &= ~(1ull << v);
+        alive &= ~victims;
         owner = lane < n_mine && ((alive >> lane) & 1ull) != 0ull;
         replay = 1u;
         if (alive == 0ull) spilled = true;  // nothing left here
@@ -1481,8 +1497,26 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
     // As bitmask rows: each row is built in LDS (in slices of the scratch buffer's size for automata whose row is longer)
     // and stored ONCE with 8-byte stores — no zeroing in the prologue, no global atomics.
     constexpr uint32_t SLICE = L::LISTW & ~1u;
+    // which streams have list entries at all (wave-uniform): the rows of the others are zero but for the folded state's bit and
+    // are stored without the detour through LDS (inputs that rarely touch a pattern: nearly all of them)
+    if (lane < 2u) slotw[lane] = 0u;
+    wave_sync();
+    for (uint32_t li = lane; li < N; li += 64u) {
+      const uint32_t es = (clist[li] >> SID_SHIFT) & SID_BITS;
+      atomicOr(&slotw[es >> 5], 1u << (es & 31u));
+    }
+    wave_sync();
+    const unsigned long long has = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)slotw[S > 32 ? 1 : 0]) << 32) * (S > 32 ? 1ull : 0ull) |
+                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)slotw[0]);
+    const uint32_t pin_w = pin_in ? cq->pin_state >> 5 : 0xFFFFFFFFu, pin_b = pin_in ? 1u << (cq->pin_state & 31u) : 0u;
     for (uint32_t sl = 0; sl < n_mine; sl++) {
       if (((alive >> sl) & 1ull) == 0ull) continue;  // (wave-uniform) finished by the wave kernel
+      if (((has >> sl) & 1ull) == 0ull) {
+        uint2* row8 = reinterpret_cast<uint2*>(cq->final_active + (size_t)(stream0 + sl) * cq->nw64x2);
+        for (uint32_t w = lane; w < cq->nw64x2 / 2u; w += 64u)
+          row8[w] = make_uint2(2u * w == pin_w ? pin_b : 0u, 2u * w + 1u == pin_w ? pin_b : 0u);
+        continue;
+      }
       for (uint32_t w0 = 0; w0 < cq->nw64x2; w0 += SLICE) {
         const uint32_t nwords = cq->nw64x2 - w0 < SLICE ? cq->nw64x2 - w0 : SLICE;
         wave_sync();
