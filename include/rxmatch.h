@@ -229,7 +229,9 @@ typedef struct rx_result {
   uint64_t* match_count_total; /* [size]: match_count summed over streams                 */
   uint32_t* anymatch;        /* [n_streams][anymatch_stride]: bit k (word k>>5, bit k&31)
                                 set iff some accept state was active in pass k            */
-  size_t anymatch_stride;    /* in u32 words, >= ceil(n_passes/32)                        */
+  size_t anymatch_stride;    /* in u32 words, >= ceil(n_passes/32); a multiple of 8 that equals
+                                ceil(ceil(max passes / 32) / 8) * 8 of the plan is copied flat,
+                                any other pitch row by row                                 */
   uint64_t* final_active;    /* [n_streams][ceil(size/64)]: S after the last pass's byte  */
   rx_stats stats;            /* out */
   /* The same final sets as compact lists (the plan must have been created with want_final): the states of

@@ -498,7 +498,9 @@ extern "C" int rx_plan_create(const rx_nfa* nfa, const rx_opts* opts, size_t max
   p->sets_clean = true;
   PLCHK(hipMalloc((void**)&p->d_events, std::max<size_t>(events_cap, 1) * sizeof(rx_event)));
   if (p->want_mc) PLCHK(hipMalloc((void**)&p->d_mc, max_streams * size * sizeof(uint32_t)));
-  p->am_stride = (size_t)((passes_for(max_stream_len, RX_MODE_FULL) + 31) / 32);
+  // rows of the plan's any-match bitmap: padded to a multiple of eight words, so that the pack kernel's 256-pass groups are
+  // aligned 32-byte sectors (a caller whose anymatch_stride is the same gets flat copies, any other stride row-by-row ones)
+  p->am_stride = ((size_t)((passes_for(max_stream_len, RX_MODE_FULL) + 31) / 32) + 7) & ~(size_t)7;
   if (p->want_am) PLCHK(hipMalloc((void**)&p->d_am, max_streams * p->am_stride * sizeof(uint32_t)));
   if (p->want_final) PLCHK(hipMalloc((void**)&p->d_final, max_streams * nw64x2 * sizeof(uint32_t)));
 #undef PLCHK

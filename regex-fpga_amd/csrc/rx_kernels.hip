@@ -849,7 +849,11 @@ struct PackLayout {
   // 64 input bytes (as byte classes) per stream; look-ahead builds (PRUNE, FOLD): + byte 64 = first class of the next
   // chunk (look-ahead at the window's last byte) + a pad word that keeps the stride odd
   static constexpr uint32_t WINW = (PRUNE || FOLD) ? 18 : 16;
-  static constexpr uint32_t STRIDE = 2u * FW + WINW + 1u;   // + any-match word; odd => banks spread
+  // any-match bits of 256 passes per stream: eight words, stored as ONE aligned 32-byte group by the stream's owner lane (a
+  // lone dword store costs 32 bytes of HBM write traffic on gfx950: tools/write_calib.hip; round 2 stored 33 of them per
+  // stream, 69 MB for 8.7 MB of bits)
+  static constexpr uint32_t AMW = 8;
+  static constexpr uint32_t STRIDE = (2u * FW + WINW + AMW) | 1u;   // odd => banks spread
   static constexpr uint32_t LISTW = CAPW + 128u;            // a sweep appends at most 128 entries past CAPW: no bounds check
   // lists, stream regions, spill slots; FOLD: + which of the window's 64 passes have an emission of the folded state
   static constexpr uint32_t WAVE_WORDS = 2u * LISTW + S * STRIDE + S + (FOLD ? 2u : 0u);
@@ -1027,13 +1031,21 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
     if (FOLD) busy = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)busyw[1]) << 32) |
                      (uint32_t)__builtin_amdgcn_readfirstlane((int)busyw[0]);
   };
-  // per-pass any-match bits of 32 passes: one word per stream, stored by the stream's owner lane
-  auto store_anymatch = [&](uint32_t word) {
+  // per-pass any-match bits of 256 passes: words [8 * group, 8 * group + 8) of every stream, stored by its owner lane.  The
+  // plan pads the rows of its bitmap to a multiple of eight words, so a group is one aligned 32-byte sector.
+  auto store_anymatch = [&](uint32_t group) {
     wave_sync();
     if (owner) {
       uint32_t* am = sreg0 + lane * L::STRIDE + 2u * L::FW + L::WINW;
-      p.anymatch[(size_t)(stream0 + lane) * p.anymatch_stride + word] = *am;
-      *am = 0u;
+      uint32_t* dst = p.anymatch + (size_t)(stream0 + lane) * p.anymatch_stride + 8u * group;
+      if ((p.anymatch_stride & 7u) == 0u) {
+        reinterpret_cast<uint4*>(dst)[0] = make_uint4(am[0], am[1], am[2], am[3]);
+        reinterpret_cast<uint4*>(dst)[1] = make_uint4(am[4], am[5], am[6], am[7]);
+      } else {  // (a bitmap with another pitch: word by word, as far as the row goes)
+        for (uint32_t w = 0; w < L::AMW && 8u * group + w < p.anymatch_stride; w++) dst[w] = am[w];
+      }
+#pragma unroll
+      for (uint32_t w = 0; w < L::AMW; w++) am[w] = 0u;
     }
     wave_sync();
   };
@@ -1156,7 +1168,7 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
           const bool acc = (e & RXE_ACCEPT) != 0u;
           uint32_t dummy = 0;
           emit_events(p, acc, s, stream0 + sid, k, lane, dummy);
-          if (acc) atomicOr(&sreg[2u * L::FW + L::WINW], 1u << (k & 31u));
+          if (acc) atomicOr(&sreg[2u * L::FW + L::WINW + ((k >> 5) & (L::AMW - 1u))], 1u << (k & 31u));
         }
       };
       if (!consume) {  // RX_MODE_FULL's last pass: nothing but the pulses
@@ -1355,8 +1367,11 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
         if (i_leave) {
           cq->spill_streams[my_slot] = stream0 + lane;
           cq->spill_k[my_slot] = k;
-          if (cq->anymatch)
-            cq->anymatch[(size_t)(stream0 + lane) * cq->anymatch_stride + (k >> 5)] = sreg0[lane * L::STRIDE + 2u * L::FW + L::WINW];
+          if (cq->anymatch) {  // the words of the current 256-pass group up to the one of pass k (which the wave kernel reads back)
+            const uint32_t* am = sreg0 + lane * L::STRIDE + 2u * L::FW + L::WINW;
+            uint32_t* dst = cq->anymatch + (size_t)(stream0 + lane) * cq->anymatch_stride + ((k >> 8) << 3);
+            for (uint32_t w = 0; w <= ((k >> 5) & (L::AMW - 1u)); w++) dst[w] = am[w];
+          }
         }
         __threadfence();
         wave_sync();
@@ -1424,16 +1439,16 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
         pass(k, std::true_type{});
         k += 1u - replay;  // (a stream was evicted: the same pass again for the others)
       } while (k < k32 && !spilled);
-      if (!spilled && p.anymatch && (k & 31u) == 0u) store_anymatch((k >> 5) - 1u);
+      if (!spilled && p.anymatch && (k & 255u) == 0u) store_anymatch((k >> 8) - 1u);
       if (LOOK && (k & 63u) == 32u) stash_next_first();
     }
   }
   while (k < p.n_passes && !spilled) {  // RX_MODE_FULL: pass N
     pass(k, std::false_type{});
     k++;
-    if (p.anymatch && (k & 31u) == 0u) store_anymatch((k >> 5) - 1u);
+    if (p.anymatch && (k & 255u) == 0u) store_anymatch((k >> 8) - 1u);
   }
-  if (!spilled && p.anymatch && (k & 31u) != 0u) store_anymatch(k >> 5);
+  if (!spilled && p.anymatch && (k & 255u) != 0u) store_anymatch(k >> 8);
   if (PROF && lane == 0) {
     for (int q = 0; q < 7; q++) atomicAdd(&p.counters[8 + q], t_sum[q]);
     // wave 0 only: [63:32] shader cycles / 64, [31:0] 100 MHz ticks, both over the whole wave

@@ -279,7 +279,8 @@ class _Out:
         self.ev = np.zeros(max(events_cap, 1), dtype=EVENT_DT) if events_cap else None
         self.mc = np.zeros((n_streams, nfa.size), np.uint32) if want_match_count else None
         self.tot = np.zeros(nfa.size, np.uint64) if want_total else None
-        self.am_stride = max((self.npass + 31) // 32, 1)
+        # (rows padded to a multiple of eight words: the plan's own pitch, so that the copies are flat; readers slice [:, :ceil(npass/32)])
+        self.am_stride = (max((self.npass + 31) // 32, 1) + 7) & ~7
         self.am = np.zeros((n_streams, self.am_stride), np.uint32) if want_anymatch else None
         # compact_final = capacity (entries) of the list form of the final sets (rx_plan_run); the bitmask rows are then left out
         self.fin = np.zeros((n_streams, nfa.nw64), np.uint64) if (want_final and not compact_final) else None
@@ -307,7 +308,7 @@ class _Out:
         r, s = self.r, self.r.stats
         return dict(events=self.ev[:r.n_events] if self.ev is not None else None, n_events=int(s.n_events),
                     events_overflow=bool(r.events_overflow), match_count=self.mc, match_count_total=self.tot,
-                    anymatch=self.am, final_active=self.fin,
+                    anymatch=self.am[:, :max((self.npass + 31) // 32, 1)] if self.am is not None else None, final_active=self.fin,
                     final_states=self.fst[:r.n_final_states] if self.fst is not None else None, final_off=self.foff,
                     final_cnt=self.fcnt, final_states_overflow=bool(r.final_states_overflow),
                     stats=dict(n_passes=int(s.n_passes), n_events=int(s.n_events), sum_active=int(s.sum_active),
