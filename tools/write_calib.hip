@@ -27,6 +27,24 @@ __global__ void scattered4(uint32_t* p, uint32_t n_streams, uint32_t stride, uin
 struct Ev { uint32_t a, b, c; };
 __global__ void store12(Ev* p, size_t n) { size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; if (i < n) { Ev e{1, 2, 3}; p[i] = e; } }
 
+// the input windows: lane = 4 * slot + part reads bytes [64 * chunk + 16 * part, + 16) of stream `slot` (rows `pitch` bytes apart),
+// 16 streams per wave-load, as rx_sym_pack_kernel's load_win does; every byte of n_streams x pitch is read once
+__global__ void read_win(const uint8_t* p, uint32_t n_streams, uint32_t pitch, uint32_t* sink) {
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+  const uint32_t slot = wave * 16u + (lane >> 2), part = lane & 3u;
+  if (slot >= n_streams) return;
+  uint32_t acc = 0;
+  for (uint32_t chunk = 0; chunk < pitch / 64u; chunk++) {
+    const uint4 q = *reinterpret_cast<const uint4*>(p + (size_t)slot * pitch + chunk * 64u + part * 16u);
+    acc ^= q.x ^ q.y ^ q.z ^ q.w;
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
+__global__ void read16(const uint4* p, size_t n, uint32_t* sink) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) { const uint4 q = p[i]; if ((q.x ^ q.y ^ q.z ^ q.w) == 0x12345678u) sink[0] = 1; }
+}
+
 int main() {
   const size_t bytes = 64u << 20;
   void* d;
@@ -41,6 +59,12 @@ int main() {
   hipLaunchKernelGGL(rows8, dim3(n_rows / 4), dim3(256), 0, 0, (uint32_t*)d, n_rows, row_words);
   for (uint32_t w = 0; w < 33; w++)  // 65 536 streams x 33 any-match words = 8.65 MB in all
     hipLaunchKernelGGL(scattered4, dim3(65536 / 256), dim3(256), 0, 0, (uint32_t*)d, 65536u, 33u, w);
+  // reads (run with --pmc FETCH_SIZE): 64 MiB as the pack kernel's input windows, then as a plain 16-B-per-lane stream; the
+  // buffer was last written by the kernels above and is far larger than L2, the 256 MiB memset in between evicts the rest
+  CHECK(hipMemset((char*)d + (128u << 20), 0, 128u << 20));
+  hipLaunchKernelGGL(read_win, dim3(65536 / 16 / 4), dim3(256), 0, 0, (const uint8_t*)d, 65536u, 1024u, (uint32_t*)d + (255u << 18));
+  CHECK(hipMemset((char*)d + (128u << 20), 1, 128u << 20));
+  hipLaunchKernelGGL(read16, dim3((unsigned)(bytes / 16 / 256)), dim3(256), 0, 0, (const uint4*)d, bytes / 16, (uint32_t*)d + (255u << 18));
   CHECK(hipDeviceSynchronize());
   printf("bytes written: store16/8/4 %zu each, store12 %zu, rows8 %zu, scattered4 %u per launch x 33 launches\n", bytes, bytes / 12 * 12,
          (size_t)n_rows * row_words * 4, 65536u * 4u);
