@@ -246,8 +246,13 @@ def main():
             ent = None
         if ent is not None:
             if ent.get("src_sha16") == kernel_source_sha16():
-                traffic, pmc = ent.get("hbm_bytes_per_launch"), ent.get("pmc")
-                traffic_note = ent.get("source", "")
+                # FETCH_SIZE counts the input windows (16 B per lane, 64 B per stream and load) at exactly HALF their bytes on
+                # gfx950 (tools/write_calib.hip: 32 780 KB for 64 MiB read in this very pattern; MI355X_MICROARCH.md says the same
+                # for wide streaming reads) and WRITE_SIZE is exact for the kernel's stores: the input's other half is added back
+                traffic, pmc = ent.get("hbm_bytes_per_launch") + (ns * sl) // 2, ent.get("pmc")
+                traffic_note = (ent.get("source", "") + f"; raw counters: FETCH_SIZE {ent.get('fetch_bytes')} B + WRITE_SIZE "
+                                f"{ent.get('write_bytes')} B; corrected = raw + half of the {ns * sl} input bytes, which the "
+                                "counter tallies at 64 B per 128-B request (tools/write_calib.hip, profiles/r03_sym_pack_auto)")
             else:
                 traffic_note = (f"profiles/traffic.json[{tkey}] was measured on another version of the kernel source "
                                 f"({ent.get('src_sha16')}): STALE, not reported")
@@ -275,8 +280,11 @@ def main():
                      "frac": round(hbm_gbs / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_note": traffic_note,
                      "compulsory_hbm_bytes_per_launch": compulsory,
                      "kernel_ms_avg": round(kavg_ms, 4), "kernel_ms_min": round(kmin, 4), "kernel_ms_max": round(kmax, 4),
-                     "limiter": "issue + dependent latency per pass, not HBM: the table and its slice index are cache-resident, "
-                                "compulsory HBM traffic is ~2 B per input byte (input + final sets + bitmap)",
+                     "limiter": "not HBM: five dependent memory round trips per pass (list entry, class byte, slice gather - ~900 cycles "
+                                "outstanding, 528 of them inside the vector L1 although L2 answers in 138 - two filter atomics, appends) "
+                                "with five in-order wavefronts per SIMD; 61 % of the wave-cycles wait on memory counters, no unit is "
+                                "saturated on average (DESIGN.md 3.4, profiles/r03_issue_ceiling); compulsory HBM traffic is ~2 B per "
+                                "input byte (input + final sets + bitmap)",
                      "pmc": pmc,
                      # SURVEY 8d's figure: what the FPGA design's row-by-row reads would have moved for the same work
                      "effective_vs_fpga_row_bytes": {"alg_bytes_per_launch": alg_bytes, "GBs": round(eff_gbs, 2),
@@ -423,6 +431,35 @@ def main():
             bp.close()
             del d_s
         out["small_batches_T"] = small
+        # What RX_KERNEL_AUTO's probes cost a fresh plan (first launch of a shape: sample launches + timed candidates + stream
+        # synchronisation), and what a launch costs once the shape is tuned (rx_plan_tune, RX_OPT_NO_PROBE): host wall clock
+        # from the call to the completed kernel, 4 096 x 1 KB (a shape where AUTO times three candidates) and the headline shape
+        probe = {}
+        for sn in (4096, ns):
+            srows = rows[:sn]
+            d_s = torch.from_numpy(srows).to(dev)
+            fp = rx.Plan(nfa, sn, sl, **common)
+            fp.set_device_input(d_s.data_ptr(), sn, sl, sl, keepalive=d_s)
+            torch.cuda.synchronize()
+            t_p = time.perf_counter()
+            fp.launch()
+            fp.sync()
+            first_ms = (time.perf_counter() - t_p) * 1e3
+            fp.close()
+            tp = rx.Plan(nfa, sn, sl, **dict(common, flags=a.flags | rx.host.OPT_NO_PROBE))
+            tp.set_device_input(d_s.data_ptr(), sn, sl, sl, keepalive=d_s)
+            tp.tune()
+            tp.launch()
+            tp.sync()
+            t_p = time.perf_counter()
+            tp.set_device_input(d_s.data_ptr(), sn, sl, sl, keepalive=d_s)
+            tp.launch()
+            tp.sync()
+            tuned_ms = (time.perf_counter() - t_p) * 1e3
+            tp.close()
+            del d_s
+            probe[f"{sn}x{sl}"] = {"first_launch_with_probes_ms": round(first_ms, 3), "launch_on_tuned_plan_ms": round(tuned_ms, 3)}
+        out["auto_probe_cost"] = probe
         # Hand-off mix: what streams cost whose active set outgrows the pack kernel's wave-wide list.  One
         # stream in 64 enters a 220-state trap grafted onto the shipped table (workloads.table_with_trap; no input makes a
         # snort_16 stream do that on its own) and is finished by the wave kernel; since round 3 ONLY that stream leaves its
