@@ -1,6 +1,6 @@
 // CPU walk of the register kernel's tables over one trace: how often a pass needs the placement path, and for what.
 // build: g++ -O2 -std=c++17 -Iregex-fpga_amd/csrc -Iinclude tools/reg_sim.cpp regex-fpga_amd/csrc/rx_host.cpp -o /tmp/reg_sim
-// usage: /tmp/reg_sim table.coe trace.mem [n]
+// usage: /tmp/reg_sim table.coe trace.mem [n [window]]   (window: the set is reset every `window` bytes, like the T workload's streams)
 #include <cstdio>
 #include <algorithm>
 #include <cstdlib>
@@ -21,6 +21,7 @@ int main(int argc, char** argv) {
   std::vector<uint8_t> tr;
   if (rxh_read_file(argv[2], &mt) || rxh_parse_mem_text(mt.data(), mt.size(), &tr)) return 1;
   size_t n = argc > 3 ? atol(argv[3]) : 200000;
+  const size_t win = argc > 4 ? atol(argv[4]) : 0;
   if (n > tr.size()) n = tr.size();
   const uint32_t ncls = h.n_classes, size = h.size, FREE = size;
   printf("size %u classes %u pin %u fold %d\n", size, ncls, h.pin_state, (int)!h.pin_tab.empty());
@@ -69,8 +70,9 @@ int main(int argc, char** argv) {
   std::map<uint32_t, unsigned long long> hot;
   for (size_t k = 0; k + 1 < n; k++) {  // tb-compat: passes 0..n-2
     const uint32_t c = h.byte_class[tr[k]], cn = h.byte_class[tr[k + 1]];
+    if (win && k % win == 0) e.assign(1, 0u);
     uint32_t vA = 0;
-    if (!h.pin_tab.empty() && k >= 1) vA = h.pin_tab[(size_t)c * (ncls + 1) + (k + 2 < n ? cn : ncls)];
+    if (!h.pin_tab.empty() && (win ? k % win : k) >= 1) vA = h.pin_tab[(size_t)c * (ncls + 1) + (k + 2 < n ? cn : ncls)];
     std::vector<uint32_t> nx, cand_nodup, cand_dup, lists;
     int ne = 0, nd = 0, no = 0;
     { int any = 0; for (uint32_t s : e) { if (cplx[s] == 1) cl1++, any = 1; if (cplx[s] == 2) cl2++, any = 1; } cpass += any; }
