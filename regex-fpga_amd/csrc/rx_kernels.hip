@@ -1771,6 +1771,9 @@ __global__ void __launch_bounds__(512) rx_sym_res_kernel(const RxParams p) {
     const uint32_t need = look ? (xf >> (16u + cn7)) & 1u : xf >> 31;
     // a member of D leaves its lane: its bit goes
     if (dbit != 0u && e != e_in) {
+#ifdef RX_RES_DEBUG
+      if (wave == 4u && k <= 3u) printf("[res] pass %u lane %u slot %u: state %u leaves, clears bit %08x at %u\n", k, lane, sid, e_in, dbit, dwa);
+#endif
       atomicAnd(region(dwa), ~dbit);
       dbit = 0u;
     }
@@ -1785,6 +1788,10 @@ __global__ void __launch_bounds__(512) rx_sym_res_kernel(const RxParams p) {
       uint32_t oA = 0u, oB = 0u;
       if (cA != 0u && dA != 0u) oA = atomicOr(region(sbo + ((dA >> 5) << 2)), 1u << (dA & 31u));
       if (cB != 0u && dB != 0u) oB = atomicOr(region(own_sbo + ((dB >> 5) << 2)), 1u << (dB & 31u));
+#ifdef RX_RES_DEBUG
+      if (wave == 4u && k <= 3u && cA != 0u) printf("[res] pass %u lane %u slot %u: candidate A state %u d %u old %08x (from state %u)\n", k, lane, sid, xs & 0xFFFFu, dA, oA, e_in);
+      if (wave == 4u && k <= 3u && cB != 0u) printf("[res] pass %u lane %u slot %u: candidate B state %u d %u old %08x\n", k, lane, own_slot, vA & 0xFFFFu, dB, oB);
+#endif
       cA &= ((oA >> (dA & 31u)) & 1u) ^ 1u;
       cB &= ((oB >> (dB & 31u)) & 1u) ^ 1u;
     }
@@ -1815,6 +1822,10 @@ __global__ void __launch_bounds__(512) rx_sym_res_kernel(const RxParams p) {
       const uint32_t best = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
       if (best == 0u) { spilled = 1u; return; }  // (cannot happen: an overflow has live streams)
       const uint32_t v = 63u - (best & 63u);
+#ifdef RX_RES_DEBUG
+      if (lane == 0) printf("[res] wave %u pass %u: stream slot %u leaves (%u lanes + wishes)\n", wave, kc, v, (best >> 6) - 1u);
+      if (ei != FREE && si == v) printf("[res]   S_k member: lane %u state %u\n", lane, ei);
+#endif
       unsigned long long b = 0;
       if (lane == 0) b = atomicAdd(cq->spill_count, 1ull);
       const uint32_t slot = bcast((uint32_t)b, 0);
@@ -1839,9 +1850,15 @@ __global__ void __launch_bounds__(512) rx_sym_res_kernel(const RxParams p) {
         if (e != FREE) { e = FREE; accf = 0u; }
         dbit = 0u;
         cA = 0u;
+        if (lA) lj = 0u;  // (an interrupted walk that is cancelled must not leave its position behind for the lane's next list)
         lA = 0u;
       }
-      if (lane == v) { cB = 0u; lB = 0u; own = 0u; }
+      if (lane == v) {
+        if (lB) lj = 0u;
+        cB = 0u;
+        lB = 0u;
+        own = 0u;
+      }
       for (uint32_t w = lane; w < DW; w += 64u) sreg0[v * STRIDE + w] = 0u;
       alive &= ~(1ull << v);
       if (alive == 0ull) spilled = 1u;
@@ -1881,6 +1898,9 @@ __global__ void __launch_bounds__(512) rx_sym_res_kernel(const RxParams p) {
               if ((bcast(old, 0) >> (d & 31u)) & 1u) continue;  // already in the set
             }
             const uint32_t dst = (uint32_t)__builtin_ctzll(mfree);
+#ifdef RX_RES_DEBUG
+            if (wave == 4u && k <= 3u && lane == 0) printf("[res] pass %u: list target state %u of slot %u (d %u) into lane %u\n", k, tw & 0xFFFFu, tsid, d, dst);
+#endif
             if (lane == dst) {
               e = tw & 0xFFFFu;
               accf = (tw >> 30) & 1u;
@@ -1926,6 +1946,9 @@ __global__ void __launch_bounds__(512) rx_sym_res_kernel(const RxParams p) {
       if (e == FREE && rf < nA + nB) {
         const uint4 t = scr4[rf];
         const uint32_t d = (t.x >> 16) & 0x3FFu;
+#ifdef RX_RES_DEBUG
+        if (wave == 4u && k <= 3u) printf("[res] pass %u: lane %u takes state %u of slot %u (d %u)\n", k, lane, t.x & 0xFFFFu, t.y, d);
+#endif
         e = t.x & 0xFFFFu;
         accf = (t.x >> 30) & 1u;
         sid = t.y;

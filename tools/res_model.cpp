@@ -45,6 +45,12 @@ int main(int argc, char** argv) {
       if (!(skip_first && k == k0)) for (uint32_t st : cur) if (is_acc(st)) out.insert(Ev(s, k, st));
       if (k >= n_consume) break;
       const uint32_t c = h.byte_class[rows[(size_t)s * sl + k]];
+      if (getenv("RES_MODEL_TRACE") && (int)s == atoi(getenv("RES_MODEL_TRACE")) && k <= 4 && k0 == 0) {
+        const uint32_t cn = k + 1 < sl ? h.byte_class[rows[(size_t)s * sl + k + 1]] : 0;
+        printf("[exact] stream %u pass %u class %u next %u:", s, k, c, cn);
+        for (uint32_t st : cur) printf("  %u{sym %08x fast %08x tgt %08x}", st, h.symidx_c[(size_t)st * ncls + c], h.res_idx[((size_t)st * ncls + c) * 2], h.res_idx[((size_t)st * ncls + c) * 2 + 1]);
+        printf("\n");
+      }
       std::set<uint32_t> nx;
       for (uint32_t st : cur) {
         const uint32_t w = h.symidx_c[(size_t)st * ncls + c];
@@ -101,8 +107,10 @@ int main(int argc, char** argv) {
         for (uint32_t s2 = 0; s2 < S; s2++) if (alive[s2] && cnt[s2] + 1 > best) { best = cnt[s2] + 1; v = (int)s2; }
         if (v < 0) { spilled = true; return; }
         evictions++;
+        if (getenv("RES_MODEL_VERBOSE")) printf("[model] wave %u pass %u: stream slot %d leaves (%u lanes + wishes)\n", stream0 / S, k, v, best - 1);
         std::set<uint32_t> Sk;
         for (uint32_t l = 0; l < 64; l++) if (e_in[l] != FREE && sid_in[l] == (uint32_t)v) Sk.insert(e_in[l]);
+        if (getenv("RES_MODEL_VERBOSE")) for (uint32_t l = 0; l < 64; l++) if (e_in[l] != FREE && sid_in[l] == (uint32_t)v) printf("[model]   S_k member: lane %u state %u\n", l, e_in[l]);
         if (k >= 1) Sk.insert(h.pin_state);
         exact_from(stream0 + v, Sk, k, true, got, &fin_got[stream0 + v]);
         for (uint32_t l = 0; l < 64; l++) { if (sid[l] == (uint32_t)v) { if (e[l] != FREE) { e[l] = FREE; acc[l] = 0; } dnum[l] = 0; candA[l] = 0; listA[l] = 0; } }
