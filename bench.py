@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--workload", choices=["T", "U", "R", "L"], default=None,
                     help="T trace windows (headline), U uniform bytes, R synthetic ~10k-state ruleset (second stand-in for "
                          "configs[4]), L the other shipped automaton (l7-filter) on windows of its own traces")
-    ap.add_argument("--kernel", default="auto", choices=["auto", "csr_wave", "sym_wave", "sym_group", "sym_pack", "dfa", "sym_reg", "sym_res"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "csr_wave", "sym_wave", "sym_group", "sym_pack", "dfa", "sym_reg"])
     ap.add_argument("--group-lanes", type=int, default=0)
     ap.add_argument("--flags", type=int, default=0, help="rx_opts.flags (RX_OPT_* bits: A/B and diagnostic switches)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="cap on oracle threads (box share: 16 per GPU)")
@@ -157,7 +157,7 @@ def main():
     wl = rx.workloads
     kern = {"auto": rx.KERNEL_AUTO, "csr_wave": rx.KERNEL_CSR_WAVE, "sym_wave": rx.KERNEL_SYM_WAVE,
             "sym_group": rx.KERNEL_SYM_GROUP, "sym_pack": rx.KERNEL_SYM_PACK, "dfa": rx.KERNEL_DFA,
-            "sym_reg": rx.KERNEL_SYM_REG, "sym_res": rx.KERNEL_SYM_RES}[a.kernel]
+            "sym_reg": rx.KERNEL_SYM_REG}[a.kernel]
     if a.workload == "R":  # second stand-in for configs[4]: synthetic ruleset compiled by rx_compile_patterns
         traces = wl.synthetic_ruleset()
         nfa = rx.Nfa.compile(traces)

@@ -147,15 +147,6 @@ enum {
                              state is active (RX_OPT_REG_NO_SKIP selects the plain one).  More than 64 active states:
                              hand-off to RX_KERNEL_SYM_WAVE.  With collect_stats or a caller-supplied start set
                              RX_KERNEL_SYM_WAVE runs instead.                                                  */
-  ,
-  RX_KERNEL_SYM_RES = 7   /* S streams per wavefront (rx_opts.group_lanes = S: 8/16/24/32/48, default 16), every lane HOLDS
-                             one (stream, state) entry in registers and updates it in place from the register kernel's kind of
-                             index; what needs a lane of its own is handed to the free lanes through one LDS scratch line;
-                             duplicates are excluded by one exact bit per (stream, state that can be produced twice) in LDS.
-                             Needs an automaton with a foldable `.*` state, < 65 536 states and < 1 024 states that can be
-                             produced twice, streams that start from reset and no statistics: RX_KERNEL_SYM_WAVE runs
-                             instead otherwise.  A stream that would need more lanes than are free leaves alone for
-                             RX_KERNEL_SYM_WAVE (as in RX_KERNEL_SYM_PACK).                                      */
 };
 
 typedef struct rx_opts {

@@ -10,4 +10,4 @@ The directory name has a hyphen, so import it with
 """
 from . import host, sharding, testbench, workloads  # noqa: F401
 from .host import (MODE_FULL, MODE_TB_COMPAT, KERNEL_AUTO, KERNEL_CSR_WAVE, KERNEL_SYM_WAVE,  # noqa: F401
-                   KERNEL_SYM_GROUP, KERNEL_SYM_PACK, KERNEL_DFA, KERNEL_SYM_REG, KERNEL_SYM_RES, Nfa, Plan, RxError, load_mem, match, match_sharded, lib_path)
+                   KERNEL_SYM_GROUP, KERNEL_SYM_PACK, KERNEL_DFA, KERNEL_SYM_REG, Nfa, Plan, RxError, load_mem, match, match_sharded, lib_path)

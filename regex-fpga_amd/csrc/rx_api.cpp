@@ -73,7 +73,6 @@ struct DevTables {
   uint32_t *symidx_p = nullptr, *ovf_dir = nullptr;  // look-ahead pruning tables (pack kernel), may stay null
   uint32_t* pin_tab = nullptr;                       // folding table of the pinned state (pack kernel), may stay null
   uint32_t* regidx = nullptr;                        // register kernel's index, may stay null (huge automata)
-  uint32_t *res_idx = nullptr, *res_pin = nullptr, *res_ovf = nullptr;  // resident-entry kernel's tables, may stay null
   uint32_t* byte_class = nullptr;
   // lazy-DFA cache (allocated by the first RX_KERNEL_DFA launch)
   uint32_t *dfa_trans = nullptr, *dfa_pool = nullptr, *dfa_hash = nullptr, *dfa_hdr = nullptr;
@@ -182,9 +181,6 @@ extern "C" void rx_nfa_free(rx_nfa* nfa) {
     (void)hipFree(kv.second.ovf_dir);
     (void)hipFree(kv.second.pin_tab);
     (void)hipFree(kv.second.regidx);
-    (void)hipFree(kv.second.res_idx);
-    (void)hipFree(kv.second.res_pin);
-    (void)hipFree(kv.second.res_ovf);
     (void)hipFree(kv.second.byte_class);
     (void)hipFree(kv.second.dfa_trans);
     (void)hipFree(kv.second.dfa_pool);
@@ -262,11 +258,6 @@ static int get_dev_tables(const rx_nfa* cnfa, int device, DevTables* out) {
   if (!nfa->h.ovf_dir.empty() && (rc = upload_vec(nfa->h.ovf_dir, &t.ovf_dir))) return rc;
   if (!nfa->h.pin_tab.empty() && (rc = upload_vec(nfa->h.pin_tab, &t.pin_tab))) return rc;
   if (!nfa->h.regidx.empty() && (rc = upload_vec(nfa->h.regidx, &t.regidx))) return rc;
-  if (nfa->h.res_dwords != 0u) {
-    if ((rc = upload_vec(nfa->h.res_idx, &t.res_idx))) return rc;
-    if ((rc = upload_vec(nfa->h.res_pin, &t.res_pin))) return rc;
-    if ((rc = upload_vec(nfa->h.res_ovf, &t.res_ovf))) return rc;
-  }
   {
     std::vector<uint32_t> bc(64);
     memcpy(bc.data(), nfa->h.byte_class, 256);
@@ -704,10 +695,6 @@ static void fill_common(rx_plan* p, RxParams& a) {
   a.byte_class = p->tab.byte_class;
   a.pin_tab = p->tab.pin_tab;
   a.regidx = p->tab.regidx;
-  a.res_idx = p->tab.res_idx;
-  a.res_pin = p->tab.res_pin;
-  a.res_ovf = p->tab.res_ovf;
-  a.res_dwords = p->tab.res_idx ? p->nfa->h.res_dwords : 0u;
   a.reg_tmask = h.reg_tmask;
   a.pin_cols = h.n_classes + 1u;
   a.n_classes = h.n_classes;
@@ -1054,10 +1041,9 @@ static int prepare_launch(rx_plan* p) {
   }
   // a caller-supplied start set is a bitmask row: that is the wave kernel's dense form
   if (p->have_init && (kernel == RX_KERNEL_AUTO || kernel == RX_KERNEL_SYM_GROUP || kernel == RX_KERNEL_SYM_PACK ||
-                       kernel == RX_KERNEL_DFA || kernel == RX_KERNEL_SYM_REG || kernel == RX_KERNEL_SYM_RES))
+                       kernel == RX_KERNEL_DFA || kernel == RX_KERNEL_SYM_REG))
     kernel = RX_KERNEL_SYM_WAVE;
   if (kernel == RX_KERNEL_SYM_REG && (p->opts.collect_stats != 0 || !p->tab.regidx)) kernel = RX_KERNEL_SYM_WAVE;
-  if (kernel == RX_KERNEL_SYM_RES && (p->opts.collect_stats != 0 || !p->tab.res_idx)) kernel = RX_KERNEL_SYM_WAVE;
   p->cfg.group_lanes = auto_lanes ? auto_lanes : p->opts.group_lanes;
   rc = rx_pick_launch(kernel, h.size, a.n_streams, p->tab.cu_count, p->tab.lds_per_cu, &a, &p->cfg);
   if (rc) return rc;
@@ -1068,7 +1054,7 @@ static int prepare_launch(rx_plan* p) {
                 ((p->cfg.kernel == RX_KERNEL_SYM_PACK &&
                   ((p->opts.flags & RX_OPT_FORCE_FOLD) != 0 || (p->opts.kernel == RX_KERNEL_AUTO && p->auto_fold))) ||
                  p->cfg.kernel == RX_KERNEL_SYM_REG);  // the register kernel folds whenever the automaton allows
-  if (p->cfg.kernel == RX_KERNEL_SYM_REG || p->cfg.kernel == RX_KERNEL_SYM_RES)
+  if (p->cfg.kernel == RX_KERNEL_SYM_REG)
     p->cfg.fold = p->tab.pin_tab != nullptr;  // (their index is built for exactly that)
   if (p->cfg.fold && p->cfg.kernel == RX_KERNEL_SYM_PACK) {
     static const uint32_t fold_s[] = {8, 13, 16, 24, 32, 48, 64};
@@ -1088,7 +1074,7 @@ static int prepare_launch(rx_plan* p) {
                  ((p->opts.flags & RX_OPT_FORCE_PRUNE) != 0 ||
                   (p->opts.kernel == RX_KERNEL_SYM_PACK ? p->probe_prune : p->opts.kernel == RX_KERNEL_AUTO && p->auto_prune));
   const bool two_tier = p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK ||
-                        p->cfg.kernel == RX_KERNEL_DFA || p->cfg.kernel == RX_KERNEL_SYM_REG || p->cfg.kernel == RX_KERNEL_SYM_RES;
+                        p->cfg.kernel == RX_KERNEL_DFA || p->cfg.kernel == RX_KERNEL_SYM_REG;
   if (two_tier && (rc = ensure_spill_area(p, a))) return rc;
   if (p->cfg.kernel == RX_KERNEL_DFA) {
     if (pair) return RX_EINVAL;
@@ -1319,12 +1305,12 @@ static int plan_download(rx_plan* p, rx_result* res) {
   st.n_events = cnt[0];
   st.kernel_ms = p->last_ms;
   st.kernel_used = p->cfg.kernel;
-  st.lanes_used = (p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK || p->cfg.kernel == RX_KERNEL_SYM_RES) ? p->cfg.group_lanes : 0u;
+  st.lanes_used = (p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK) ? p->cfg.group_lanes : 0u;
   st.variant = (p->cfg.stats ? RX_VARIANT_STATS : 0u) |
                (p->cfg.kernel == RX_KERNEL_SYM_PACK && p->cfg.prune && !p->cfg.stats && p->tab.symidx_p ? RX_VARIANT_PRUNE : 0u) |
                (p->cfg.fold ? RX_VARIANT_FOLD : 0u);
   st.n_launches = (p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK ||
-                   p->cfg.kernel == RX_KERNEL_DFA || p->cfg.kernel == RX_KERNEL_SYM_REG || p->cfg.kernel == RX_KERNEL_SYM_RES) ? 2 : 1;
+                   p->cfg.kernel == RX_KERNEL_DFA || p->cfg.kernel == RX_KERNEL_SYM_REG) ? 2 : 1;
   if (p->cfg.stats) {
     st.sum_active = cnt[1];
     st.sum_edges = cnt[2];
@@ -1528,7 +1514,7 @@ static int plan_run_body(rx_plan* p, const uint8_t* bytes, size_t n_streams, siz
   HIPCHK(hipStreamSynchronize(p->stream));  // (the probe ran on the plan's own stream)
   const size_t am_need = (size_t)((p->params.n_passes + 31) / 32);
   const bool two_tier = p->cfg.kernel == RX_KERNEL_SYM_GROUP || p->cfg.kernel == RX_KERNEL_SYM_PACK ||
-                        p->cfg.kernel == RX_KERNEL_DFA || p->cfg.kernel == RX_KERNEL_SYM_REG || p->cfg.kernel == RX_KERNEL_SYM_RES;
+                        p->cfg.kernel == RX_KERNEL_DFA || p->cfg.kernel == RX_KERNEL_SYM_REG;
   for (size_t b = 1; b < n_blocks; b++)  // all uploads are queued before any download (both use the same link)
     if ((rc = upload(b))) return rc;
   // ONE capacity for the whole call: the blocks' kernels run one after the other on the kernel stream and take their
@@ -1569,7 +1555,7 @@ static int plan_run_body(rx_plan* p, const uint8_t* bytes, size_t n_streams, siz
     HIPCHK(hipEventRecord(q.k0, p->s_k));
     // compact final sets: the pack kernel (and the wave kernel behind it) writes the lists itself and builds no rows; the
     // other kernels leave rows, which a small kernel behind them turns into lists
-    const bool direct = compact && (cfg.kernel == RX_KERNEL_SYM_PACK || cfg.kernel == RX_KERNEL_SYM_RES);
+    const bool direct = compact && cfg.kernel == RX_KERNEL_SYM_PACK;
     if (direct) {
       a.fin_states = p->d_fstates;
       a.fin_cap = (uint32_t)res->final_states_cap;

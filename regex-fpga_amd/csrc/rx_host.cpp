@@ -440,73 +440,6 @@ int rxh_build(const uint32_t* W, size_t nwords, uint32_t size_or_0, RxHostNfa* o
           out->regidx[((size_t)i * ncls + k) * 2u + 1u] = w;
         }
     }
-    // ---- the resident-entry kernel's tables (rx_sym_res_kernel): the same index, every target word carrying the DENSE
-    // number of its state among the states that can be inserted twice --------------------------------------------------
-    // D = every state that is the target of some RXE_MAYDUP word.  The kernel keeps, per stream, one bit per member of D
-    // that is in the stream's set: a candidate in D is inserted with one LDS test-and-set on that bit (exact: the numbering
-    // is injective, nothing is hashed), a lane that leaves a member of D clears it — nothing is paid per pass for the
-    // states that merely stay.  Needs: folding table, < 65 536 states (target in bits 15:0, number in bits 25:16), |D| < 1024.
-    out->res_idx.clear();
-    out->res_pin.clear();
-    out->res_ovf.clear();
-    out->res_dwords = 0;
-    if (!out->regidx.empty() && !out->pin_tab.empty() && size < 65536u) {
-      std::vector<uint16_t> dnum(size, 0);  // 1-based; 0 = not in D
-      auto mark = [&](uint32_t w) { if (w & RXE_MAYDUP) dnum[w & RXE_TGT_MASK] = 1; };
-      for (uint32_t i = 0; i < size; i++)
-        for (uint32_t k = 0; k < ncls; k++) {
-          const uint32_t w = out->symidx_c[(size_t)i * ncls + k];
-          if (w & RXE_INLINE) mark(w);
-        }
-      {  // overflow lists: [count, targets...] back to back from offset 1
-        size_t at = 1;
-        while (at < out->ovf.size()) {
-          const uint32_t cnt = out->ovf[at];
-          for (uint32_t j = 0; j < cnt && at + 1u + j < out->ovf.size(); j++) mark(out->ovf[at + 1u + j]);
-          at += (size_t)cnt + 1u;
-        }
-      }
-      for (uint32_t w : out->pin_tab) if (w & RXE_INLINE) mark(w);
-      uint32_t nd = 0;
-      for (uint32_t t = 0; t < size; t++) if (dnum[t]) dnum[t] = (uint16_t)++nd;
-      if (nd < 1024u) {
-        auto with_num = [&](uint32_t w) {  // a target word: state in bits 15:0, its number in D (0 = none) in bits 25:16
-          return (w & ~0x00FF0000u) | ((uint32_t)dnum[w & RXE_TGT_MASK] << 16);
-        };
-        out->res_ovf = out->ovf;
-        {
-          size_t at = 1;
-          while (at < out->res_ovf.size()) {
-            const uint32_t cnt = out->res_ovf[at];
-            for (uint32_t j = 0; j < cnt && at + 1u + j < out->res_ovf.size(); j++) out->res_ovf[at + 1u + j] = with_num(out->res_ovf[at + 1u + j]);
-            at += (size_t)cnt + 1u;
-          }
-        }
-        out->res_pin = out->pin_tab;
-        for (uint32_t& w : out->res_pin) if (w & RXE_INLINE) w = with_num(w);
-        out->res_idx = out->regidx;
-        for (uint32_t i = 0; i < size; i++)
-          for (uint32_t k = 0; k < ncls; k++) {
-            uint32_t& fast = out->res_idx[((size_t)i * ncls + k) * 2u];
-            uint32_t& w = out->res_idx[((size_t)i * ncls + k) * 2u + 1u];
-            if (!(w & RXE_INLINE)) continue;
-            const uint32_t t = w & RXE_TGT_MASK;
-            // a lane may only move on IN PLACE to a state outside D (the bits of D are set where candidates are inserted):
-            // such a move becomes "the lane frees itself, the target asks for a lane"
-            if (dnum[t] && !(fast & RXR_NEED) && (fast & 0xFFFFu) == t && t != i) {
-              fast = size | RXR_NEED | RXR_EXTRA | ((uint32_t)((w & RXE_ACCEPT) ? 0xFFu : 0u) << 16);
-              if (!(w & RXE_ACCEPT)) {
-                uint32_t live8 = 0;
-                for (uint32_t q = 0; q < ncls; q++)
-                  if (out->symidx_c[(size_t)t * ncls + q] != 0u) live8 |= 1u << (q & 7u);
-                fast |= live8 << 16;
-              }
-            }
-            w = with_num(w);
-          }
-        out->res_dwords = (nd + 1u + 31u) / 32u;
-      }
-    }
   }
   return RX_OK;
 }

@@ -72,14 +72,6 @@ struct RxParams {
   // folding table has it for the folded state's.  reg_tmask = 0xFFFFFF otherwise (bits 23:0 value, no look-ahead).
   const uint32_t* regidx;
   uint32_t reg_tmask;
-  // resident-entry kernel (rx_sym_res_kernel): regidx / pin_tab / ovf again with every TARGET word holding the state in bits
-  // 15:0 and in bits 25:16 its 1-based number among the states that can be inserted twice (0 = cannot), and with in-place
-  // moves into such states turned into "free the lane + place the target".  res_dwords = words of the per-stream bitmap over
-  // those numbers (<= 32).  Null / 0: the automaton does not qualify (no folding table, >= 65 536 states, >= 1 024 such states).
-  const uint32_t* res_idx;
-  const uint32_t* res_pin;
-  const uint32_t* res_ovf;
-  uint32_t res_dwords;
   const uint32_t* byte_class;   // [64] words = 256 bytes: class id of every input byte
   uint32_t n_classes;
   const uint32_t* ovf;          // overflow target lists of the slice index
@@ -202,9 +194,6 @@ struct RxHostNfa {
   // RxParams::regidx; empty for automata whose table would exceed 256 MB (the register kernel is then not offered)
   std::vector<uint32_t> regidx;
   uint32_t reg_tmask = RXE_TGT_MASK;  // RxParams::reg_tmask
-  // RxParams::res_idx / res_pin / res_ovf / res_dwords (resident-entry kernel); empty / 0 when the automaton does not qualify
-  std::vector<uint32_t> res_idx, res_pin, res_ovf;
-  uint32_t res_dwords = 0;
   const uint32_t* row_ptr() const { return words.data(); }
   const uint32_t* col() const { return words.data() + size + 1; }
 };

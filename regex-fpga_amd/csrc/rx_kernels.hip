@@ -821,110 +821,6 @@ __global__ void __launch_bounds__(256) rx_sym_group_kernel(const RxParams p) {
   }
 }
 
-// ---- final active sets of the kernels that keep (stream slot, state) entries per wavefront -----------------------
-// clist[0..N): the entries (state in bits 23:0, stream slot above SID_SHIFT) of the streams that stayed with this wavefront;
-// nlist: SLICE words of scratch; slotw: S words; owner: this lane's slot is one of them; pin_in: every set also holds the
-// folded state (RxParams::pin_state), which is no entry.  Compact lists (RxParams::fin_states) or bitmask rows.
-template <int S, uint32_t SLICE, uint32_t SID_BITS>
-__device__ __forceinline__ void pack_store_final_sets(uint32_t* clist, uint32_t* nlist, uint32_t* slotw, const uint32_t N, const uint32_t lane,
-                                                      const bool owner, const unsigned long long alive, const uint32_t n_mine,
-                                                      const uint32_t stream0, const bool pin_in) {
-  constexpr uint32_t SID_SHIFT = 24;
-  const RxColdParams cq = cold_params();
-  if (cq->fin_states) {
-    // As compact lists, straight from the list entries — no bitmask row is ever built.  Per entry its rank among its
-    // stream's entries (ascending state), per stream (owner lane) the count and, FOLD, where the folded state goes; one
-    // atomic per wavefront for the space.
-    wave_sync();
-    uint32_t my_cnt = 0, pin_rank = 0;
-    for (uint32_t q = 0; q < N; q++) {
-      const uint32_t eq = clist[q];
-      const uint32_t sq = eq & RXE_TGT_MASK;
-      if (((eq >> SID_SHIFT) & SID_BITS) == lane && !(pin_in && sq == cq->pin_state)) {
-        my_cnt++;
-        if (pin_in && sq < cq->pin_state) pin_rank++;
-      }
-    }
-    if (!owner) my_cnt = 0;
-    else if (pin_in) my_cnt++;
-    uint32_t incl = my_cnt;
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
-      if (lane >= (uint32_t)d) incl += o;
-    }
-    const uint32_t total = bcast(incl, 63);
-    unsigned long long base = 0;
-    if (lane == 0 && total) base = atomicAdd(cq->fin_count, (unsigned long long)total);
-    base = ((unsigned long long)bcast((uint32_t)(base >> 32), 0) << 32) | bcast((uint32_t)base, 0);
-    const unsigned long long my_off64 = base + (incl - my_cnt);
-    const uint32_t my_off = (uint32_t)(my_off64 < cq->fin_cap ? my_off64 : cq->fin_cap);
-    if (owner) {
-      cq->fin_off[stream0 + lane] = my_off;
-      cq->fin_cnt[stream0 + lane] = my_cnt;
-      if (pin_in && my_off + pin_rank < cq->fin_cap) cq->fin_states[my_off + pin_rank] = cq->pin_state;
-    }
-    if (lane < (uint32_t)S) slotw[lane] = my_off;
-    wave_sync();
-    for (uint32_t b0 = 0; b0 < N; b0 += 64u) {
-      const uint32_t li = b0 + lane;
-      const uint32_t e = li < N ? clist[li] : 0u;
-      const uint32_t sid = (e >> SID_SHIFT) & SID_BITS, sq = e & RXE_TGT_MASK;
-      const bool valid = li < N && !(pin_in && sq == cq->pin_state);
-      uint32_t rank = (pin_in && sq > cq->pin_state) ? 1u : 0u;
-      for (uint32_t q = 0; q < N; q++) {
-        const uint32_t eq = clist[q];
-        rank += (((eq >> SID_SHIFT) & SID_BITS) == sid && (eq & RXE_TGT_MASK) < sq) ? 1u : 0u;
-      }
-      if (valid) {
-        const uint32_t o = slotw[sid] + rank;
-        if (o < cq->fin_cap) cq->fin_states[o] = sq;
-      }
-    }
-  } else if (cq->final_active) {
-    // As bitmask rows: each row is built in LDS (in slices of the scratch buffer's size for automata whose row is longer)
-    // and stored ONCE with 8-byte stores — no zeroing in the prologue, no global atomics.
-    // which streams have list entries at all (wave-uniform): the rows of the others are zero but for the folded state's bit and
-    // are stored without the detour through LDS (inputs that rarely touch a pattern: nearly all of them)
-    if (lane < 2u) slotw[lane] = 0u;
-    wave_sync();
-    for (uint32_t li = lane; li < N; li += 64u) {
-      const uint32_t es = (clist[li] >> SID_SHIFT) & SID_BITS;
-      atomicOr(&slotw[es >> 5], 1u << (es & 31u));
-    }
-    wave_sync();
-    const unsigned long long has = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)slotw[S > 32 ? 1 : 0]) << 32) * (S > 32 ? 1ull : 0ull) |
-                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)slotw[0]);
-    const uint32_t pin_w = pin_in ? cq->pin_state >> 5 : 0xFFFFFFFFu, pin_b = pin_in ? 1u << (cq->pin_state & 31u) : 0u;
-    for (uint32_t sl = 0; sl < n_mine; sl++) {
-      if (((alive >> sl) & 1ull) == 0ull) continue;  // (wave-uniform) finished by the wave kernel
-      if (((has >> sl) & 1ull) == 0ull) {
-        uint2* row8 = reinterpret_cast<uint2*>(cq->final_active + (size_t)(stream0 + sl) * cq->nw64x2);
-        for (uint32_t w = lane; w < cq->nw64x2 / 2u; w += 64u)
-          row8[w] = make_uint2(2u * w == pin_w ? pin_b : 0u, 2u * w + 1u == pin_w ? pin_b : 0u);
-        continue;
-      }
-      for (uint32_t w0 = 0; w0 < cq->nw64x2; w0 += SLICE) {
-        const uint32_t nwords = cq->nw64x2 - w0 < SLICE ? cq->nw64x2 - w0 : SLICE;
-        wave_sync();
-        for (uint32_t w = lane; w < nwords; w += 64u) nlist[w] = 0u;
-        wave_sync();
-        for (uint32_t li = lane; li < N; li += 64u) {
-          const uint32_t e = clist[li];
-          const uint32_t wd = (e & RXE_TGT_MASK) >> 5;
-          if (((e >> SID_SHIFT) & SID_BITS) == sl && wd >= w0 && wd - w0 < nwords) atomicOr(&nlist[wd - w0], 1u << (e & 31u));
-        }
-        if (pin_in && lane == 0) {
-          const uint32_t wd = cq->pin_state >> 5;
-          if (wd >= w0 && wd - w0 < nwords) atomicOr(&nlist[wd - w0], 1u << (cq->pin_state & 31u));
-        }
-        wave_sync();
-        uint2* row8 = reinterpret_cast<uint2*>(cq->final_active + (size_t)(stream0 + sl) * cq->nw64x2 + w0);
-        for (uint32_t w = lane; w < nwords / 2u; w += 64u) row8[w] = make_uint2(nlist[2u * w], nlist[2u * w + 1u]);
-      }
-    }
-  }
-}
-
 // =================================================================================================
 // Kernel 4: S streams per wavefront, lanes assigned DYNAMICALLY to (stream, state) entries
 // =================================================================================================
@@ -1561,8 +1457,101 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
   if ((FOLD || PRUNE) && lane == 0 && fold_entries) atomicAdd(&p.counters[7], fold_entries);
   // Final active sets of the streams that stayed (FPGA.v:733-737: the set that survives the last byte).  The next-list
   // buffer is dead now and serves as scratch.
-  if (!spilled)
-    pack_store_final_sets<S, (L::LISTW & ~1u), SID_BITS>(clist, nlist, slotw, N, lane, owner, alive, n_mine, stream0, FOLD && n_consume >= 1u);
+  const bool pin_in = FOLD && n_consume >= 1u;  // the folded state is in every set after the first byte
+  const RxColdParams cq = cold_params();
+  if (cq->fin_states && !spilled) {
+    // As compact lists, straight from the list entries — no bitmask row is ever built.  Per entry its rank among its
+    // stream's entries (ascending state), per stream (owner lane) the count and, FOLD, where the folded state goes; one
+    // atomic per wavefront for the space.
+    wave_sync();
+    uint32_t my_cnt = 0, pin_rank = 0;
+    for (uint32_t q = 0; q < N; q++) {
+      const uint32_t eq = clist[q];
+      const uint32_t sq = eq & RXE_TGT_MASK;
+      if (((eq >> SID_SHIFT) & SID_BITS) == lane && !(pin_in && sq == cq->pin_state)) {
+        my_cnt++;
+        if (pin_in && sq < cq->pin_state) pin_rank++;
+      }
+    }
+    if (!owner) my_cnt = 0;
+    else if (pin_in) my_cnt++;
+    uint32_t incl = my_cnt;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+      if (lane >= (uint32_t)d) incl += o;
+    }
+    const uint32_t total = bcast(incl, 63);
+    unsigned long long base = 0;
+    if (lane == 0 && total) base = atomicAdd(cq->fin_count, (unsigned long long)total);
+    base = ((unsigned long long)bcast((uint32_t)(base >> 32), 0) << 32) | bcast((uint32_t)base, 0);
+    const unsigned long long my_off64 = base + (incl - my_cnt);
+    const uint32_t my_off = (uint32_t)(my_off64 < cq->fin_cap ? my_off64 : cq->fin_cap);
+    if (owner) {
+      cq->fin_off[stream0 + lane] = my_off;
+      cq->fin_cnt[stream0 + lane] = my_cnt;
+      if (pin_in && my_off + pin_rank < cq->fin_cap) cq->fin_states[my_off + pin_rank] = cq->pin_state;
+    }
+    if (lane < (uint32_t)S) slotw[lane] = my_off;
+    wave_sync();
+    for (uint32_t b0 = 0; b0 < N; b0 += 64u) {
+      const uint32_t li = b0 + lane;
+      const uint32_t e = li < N ? clist[li] : 0u;
+      const uint32_t sid = (e >> SID_SHIFT) & SID_BITS, sq = e & RXE_TGT_MASK;
+      const bool valid = li < N && !(pin_in && sq == cq->pin_state);
+      uint32_t rank = (pin_in && sq > cq->pin_state) ? 1u : 0u;
+      for (uint32_t q = 0; q < N; q++) {
+        const uint32_t eq = clist[q];
+        rank += (((eq >> SID_SHIFT) & SID_BITS) == sid && (eq & RXE_TGT_MASK) < sq) ? 1u : 0u;
+      }
+      if (valid) {
+        const uint32_t o = slotw[sid] + rank;
+        if (o < cq->fin_cap) cq->fin_states[o] = sq;
+      }
+    }
+  } else if (cq->final_active && !spilled) {
+    // As bitmask rows: each row is built in LDS (in slices of the scratch buffer's size for automata whose row is longer)
+    // and stored ONCE with 8-byte stores — no zeroing in the prologue, no global atomics.
+    constexpr uint32_t SLICE = L::LISTW & ~1u;
+    // which streams have list entries at all (wave-uniform): the rows of the others are zero but for the folded state's bit and
+    // are stored without the detour through LDS (inputs that rarely touch a pattern: nearly all of them)
+    if (lane < 2u) slotw[lane] = 0u;
+    wave_sync();
+    for (uint32_t li = lane; li < N; li += 64u) {
+      const uint32_t es = (clist[li] >> SID_SHIFT) & SID_BITS;
+      atomicOr(&slotw[es >> 5], 1u << (es & 31u));
+    }
+    wave_sync();
+    const unsigned long long has = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)slotw[S > 32 ? 1 : 0]) << 32) * (S > 32 ? 1ull : 0ull) |
+                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)slotw[0]);
+    const uint32_t pin_w = pin_in ? cq->pin_state >> 5 : 0xFFFFFFFFu, pin_b = pin_in ? 1u << (cq->pin_state & 31u) : 0u;
+    for (uint32_t sl = 0; sl < n_mine; sl++) {
+      if (((alive >> sl) & 1ull) == 0ull) continue;  // (wave-uniform) finished by the wave kernel
+      if (((has >> sl) & 1ull) == 0ull) {
+        uint2* row8 = reinterpret_cast<uint2*>(cq->final_active + (size_t)(stream0 + sl) * cq->nw64x2);
+        for (uint32_t w = lane; w < cq->nw64x2 / 2u; w += 64u)
+          row8[w] = make_uint2(2u * w == pin_w ? pin_b : 0u, 2u * w + 1u == pin_w ? pin_b : 0u);
+        continue;
+      }
+      for (uint32_t w0 = 0; w0 < cq->nw64x2; w0 += SLICE) {
+        const uint32_t nwords = cq->nw64x2 - w0 < SLICE ? cq->nw64x2 - w0 : SLICE;
+        wave_sync();
+        for (uint32_t w = lane; w < nwords; w += 64u) nlist[w] = 0u;
+        wave_sync();
+        for (uint32_t li = lane; li < N; li += 64u) {
+          const uint32_t e = clist[li];
+          const uint32_t wd = (e & RXE_TGT_MASK) >> 5;
+          if (((e >> SID_SHIFT) & SID_BITS) == sl && wd >= w0 && wd - w0 < nwords) atomicOr(&nlist[wd - w0], 1u << (e & 31u));
+        }
+        if (pin_in && lane == 0) {
+          const uint32_t wd = cq->pin_state >> 5;
+          if (wd >= w0 && wd - w0 < nwords) atomicOr(&nlist[wd - w0], 1u << (cq->pin_state & 31u));
+        }
+        wave_sync();
+        uint2* row8 = reinterpret_cast<uint2*>(cq->final_active + (size_t)(stream0 + sl) * cq->nw64x2 + w0);
+        for (uint32_t w = lane; w < nwords / 2u; w += 64u) row8[w] = make_uint2(nlist[2u * w], nlist[2u * w + 1u]);
+      }
+    }
+  }
   if (STATS) {
     if (st_active) atomicAdd(&p.counters[1], st_active);
     if (st_edges) atomicAdd(&p.counters[2], st_edges);
@@ -1570,434 +1559,6 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
     if (st_ovf) atomicAdd(&p.counters[5], st_ovf);    // entries that met a multi-target row
     if (st_dead) atomicAdd(&p.counters[6], st_dead);  // entries out of such rows that died on the next byte
     if (st_active) atomicAdd(&p.counters[7], st_active);  // this kernel's share of counters[1]
-  }
-}
-
-// =================================================================================================
-// Kernel 7: resident entries — S streams per wavefront, every lane HOLDS one (stream, state) entry in registers
-// =================================================================================================
-// The pack kernel rebuilds its wave-wide list in every pass: list read -> class byte -> slice gather -> two filter atomics ->
-// appends, five dependent memory round trips, for entries most of which merely stay where they are (the `[^\n]*`-like states
-// of snort_16) or step on to their one successor.  Here an entry lives in a LANE (state id and stream slot in VGPRs, as the
-// register kernel keeps one stream's set) and a pass is
-//     gather {fast word, target word} of (state, class of the lane's stream's byte)  ->  state = fast word & 0xFFFF
-// with the in-place update precomputed per (state, class) exactly as for the register kernel (RxParams::res_idx): the state
-// itself if it loops on the byte, its one target if nothing else can reach that target, else "free".  What needs a lane of
-// its own — a target next to a state that stays, a target a second state could also produce, what the folded `.*` state
-// emits (looked up by the stream's OWNER lane, lane == stream slot, in the LDS copy of the folding table) — is a CANDIDATE:
-// the candidates of a pass are ranked with __ballot / mbcnt, written to an LDS scratch line (target word, stream slot, the
-// stream's next byte classes), and the free lanes, ranked the same way, pick them up: two LDS trips, no atomics, no list.
-// Duplicates: the set D of states that can be produced twice is numbered at load time (rx_host.cpp; snort_16: 708 of 9 514);
-// every stream has one bit per member of D in LDS; a candidate in D is inserted with ONE test-and-set of its bit (exact —
-// nothing is hashed), a lane whose state leaves D clears the bit, and a state that merely stays costs nothing at all.
-// Single targets get the register kernel's one byte of look-ahead (fast word bits 23:16), the folded state's emissions the
-// folding table's.  Rows with several targets and emission lists are placed by a scalar loop (rare on snort_16).
-// No free lane left: the stream that holds the most lanes leaves with S_k (the lanes' states before the pass, plus the folded
-// state) and k for the wave kernel, like a pack-kernel hand-off; the pass goes on for the others.
-// Needs RxParams::res_idx (folding table, < 65 536 states, < 1 024 states in D), streams that start from reset, no statistics.
-template <int S>
-struct ResLayout {
-  static constexpr uint32_t WINW = 18;   // 64 byte classes + the look-ahead byte (first class of the next chunk) + pad
-  static constexpr uint32_t AMW = 8;     // any-match bits of 256 passes
-  static constexpr uint32_t SCRW = 256;  // placement scratch: 64 candidates x 16 bytes (final sets: row slices)
-  static constexpr uint32_t LISTW = 64;  // final sets: the entries as a list
-  static constexpr uint32_t CMAPW = 64;
-  // per stream: D bitmap [dw] (dw = RxParams::res_dwords rounded up to even), window [WINW], any-match [AMW]; odd stride
-  __host__ __device__ static constexpr uint32_t stride(uint32_t dw) { return (dw + WINW + AMW) | 1u; }
-  __host__ __device__ static constexpr uint32_t wave_words(uint32_t dw) { return (SCRW + LISTW + S * stride(dw) + S + 3u) & ~3u; }
-};
-
-template <int S>
-__global__ void __launch_bounds__(512) rx_sym_res_kernel(const RxParams p) {
-  using L = ResLayout<S>;
-  static_assert(S >= 1 && S <= 64, "six-bit stream slot");
-  constexpr uint32_t SID_SHIFT = 24, SID_BITS = 63u;
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wib = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-  uint32_t* cmapw = lds;
-  const uint8_t* cmap = reinterpret_cast<const uint8_t*>(cmapw);
-  const uint32_t ncls = p.n_classes, pin_cols = p.pin_cols;
-  const uint32_t pin_words = (ncls * pin_cols + 3u) & ~3u;
-  const uint32_t* pintab = lds + L::CMAPW;  // [n_classes][n_classes + 1], shared by the block
-  const uint32_t DW = (p.res_dwords + 1u) & ~1u, STRIDE = L::stride(DW), STRIDE4 = STRIDE * 4u;
-  uint32_t* scr = lds + L::CMAPW + pin_words + (size_t)wib * L::wave_words(DW);  // [64][4], 16-byte aligned
-  uint32_t* clw = scr + L::SCRW;                 // [64]
-  uint32_t* sreg0 = clw + L::LISTW;              // [S][STRIDE]
-  uint32_t* slotw = sreg0 + S * STRIDE;          // [S]
-  const uint32_t WIN4 = DW * 4u, AM = DW + L::WINW;  // window (byte offset) and any-match words (word offset) inside a stream region
-  const char* __restrict__ resx = reinterpret_cast<const char*>(p.res_idx);
-  const uint32_t FREE = p.size;
-
-  zero_next_counters(p);
-  for (uint32_t w = threadIdx.x; w < L::CMAPW; w += blockDim.x) cmapw[w] = p.byte_class[w];
-  for (uint32_t w = threadIdx.x; w < ncls * pin_cols; w += blockDim.x) lds[L::CMAPW + w] = p.res_pin[w];
-  __syncthreads();  // the only block-wide barrier
-
-  const uint32_t wave = blockIdx.x * wpb + wib;
-  const uint32_t stream0 = wave * S;
-  if (stream0 >= p.n_streams) return;
-  const uint32_t n_mine = p.n_streams - stream0 < (uint32_t)S ? p.n_streams - stream0 : (uint32_t)S;
-  const uint32_t n_mine_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_mine);
-  unsigned long long alive = n_mine_s >= 64u ? ~0ull : (1ull << n_mine_s) - 1ull;  // stream slots this wavefront still handles
-  uint32_t spilled = 0u;  // (scalar) 1: every stream of the wavefront has been handed off
-  const uint32_t own_slot = lane < (uint32_t)S ? lane : 0u;
-  const uint32_t own_sbo = own_slot * STRIDE4;
-  auto region = [&](uint32_t byte_off) -> uint32_t* { return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(sreg0) + byte_off); };
-
-  // Everything below that is not the pass itself reads its kernel arguments from the kernel-argument segment where it uses
-  // them (cold_params): held in SGPRs across the pass loop they would push the loop's own scalars into lane spills.
-  constexpr uint32_t NLOAD = (S + 15) / 16;  // wave-loads per window refill: lane = 4*slot + part fetches 16 bytes
-  auto load_win = [&](uint32_t chunk, uint32_t (&o)[NLOAD][4]) {
-    const RxColdParams cq = cold_params();
-#pragma unroll
-    for (uint32_t g = 0; g < NLOAD; g++) {
-      const uint32_t slot = g * 16u + (lane >> 2), part = lane & 3u;
-      const bool have = slot < n_mine;
-      const uint8_t* bp = cq->bytes + (size_t)(stream0 + (have ? slot : 0)) * cq->stride;
-      const uint32_t off = chunk * 64u + part * 16u;
-      uint32_t v[4] = {0, 0, 0, 0};
-      if (have) {
-        if ((reinterpret_cast<uintptr_t>(bp + off) & 15u) == 0 && off + 16u <= cq->stream_len) {
-          const uint4 q = *reinterpret_cast<const uint4*>(bp + off);
-          v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-        } else {
-#pragma unroll
-          for (int w4 = 0; w4 < 4; w4++)
-            for (uint32_t b = 0; b < 4; b++)
-              if (off + 4u * w4 + b < cq->stream_len) v[w4] |= (uint32_t)bp[off + 4u * w4 + b] << (8u * b);
-        }
-      }
-#pragma unroll
-      for (int w4 = 0; w4 < 4; w4++) o[g][w4] = v[w4];
-    }
-  };
-  uint32_t nxt[NLOAD][4];
-  auto refill = [&](uint32_t k) {  // k a multiple of 64: bytes -> byte classes on the way into LDS, next window requested
-    wave_sync();
-#pragma unroll
-    for (uint32_t g = 0; g < NLOAD; g++) {
-      const uint32_t slot = g * 16u + (lane >> 2), part = lane & 3u;
-      if (slot < n_mine) {
-        uint32_t* win = sreg0 + slot * STRIDE + DW + part * 4u;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const uint32_t v = nxt[g][q];
-          win[q] = (uint32_t)cmap[v & 0xFFu] | ((uint32_t)cmap[(v >> 8) & 0xFFu] << 8) |
-                   ((uint32_t)cmap[(v >> 16) & 0xFFu] << 16) | ((uint32_t)cmap[v >> 24] << 24);
-        }
-      }
-    }
-    load_win((k >> 6) + 1u, nxt);
-    wave_sync();
-  };
-  auto stash_next_first = [&]() {  // class of the first byte of the NEXT chunk behind the window (mid-chunk: that load has landed)
-#pragma unroll
-    for (uint32_t g = 0; g < NLOAD; g++) {
-      const uint32_t slot = g * 16u + (lane >> 2);
-      if ((lane & 3u) == 0u && slot < n_mine) sreg0[slot * STRIDE + DW + 16u] = cmap[nxt[g][0] & 0xFFu];
-    }
-    wave_sync();
-  };
-  auto store_anymatch = [&](uint32_t group) {  // words [8 * group, +8) of every stream that is still here, one aligned 32-byte sector
-    const RxColdParams cq = cold_params();
-    wave_sync();
-    if (cq->anymatch && lane < n_mine && ((alive >> lane) & 1ull) != 0ull) {
-      uint32_t* am = sreg0 + lane * STRIDE + AM;
-      uint32_t* dst = cq->anymatch + (size_t)(stream0 + lane) * cq->anymatch_stride + 8u * group;
-      if ((cq->anymatch_stride & 7u) == 0u) {
-        reinterpret_cast<uint4*>(dst)[0] = make_uint4(am[0], am[1], am[2], am[3]);
-        reinterpret_cast<uint4*>(dst)[1] = make_uint4(am[4], am[5], am[6], am[7]);
-      } else {
-        for (uint32_t w = 0; w < L::AMW && 8u * group + w < cq->anymatch_stride; w++) dst[w] = am[w];
-      }
-#pragma unroll
-      for (uint32_t w = 0; w < L::AMW; w++) am[w] = 0u;
-    }
-    wave_sync();
-  };
-
-  for (uint32_t w = lane; w < S * STRIDE; w += 64u) sreg0[w] = 0u;
-  // The entry this lane holds.  Every per-lane predicate is a 0/1 INTEGER in a VGPR (bools that are changed inside the rare
-  // loops below would live as lane masks in SGPR pairs and be merged with three scalar instructions per variable and branch).
-  uint32_t own = lane < n_mine ? 1u : 0u;                   // this lane's stream slot (lane == slot) is still handled here
-  uint32_t e = own ? (p.state0_entry & 0xFFFFu) : FREE;     // FPGA.v:134-147: current = {state 0}, per stream
-  uint32_t accf = (own && (p.state0_entry & RXE_ACCEPT) != 0u) ? 1u : 0u;  // ... it is an accept state
-  uint32_t sid = own_slot, sbo = own_sbo;                   // its stream: slot and byte offset of the slot's LDS region
-  uint32_t dbit = 0u, dwa = 0u;                             // its bit in the stream's D bitmap (0: the state is not in D) and that word
-  uint32_t cw_lo = 0u, cw_hi = 0u;                          // classes of the next bytes of ITS stream, the current one lowest
-  uint32_t ow_lo = 0u, ow_hi = 0u;                          // the same for the stream this lane OWNS
-  load_win(0, nxt);
-  wave_sync();
-
-  const uint32_t n_consume = p.n_consume < p.n_passes ? p.n_consume : p.n_passes;
-
-  // accept pulses of S_k (FPGA.v:210-226); rare
-  auto pulses = [&](uint32_t k) {
-    if (wballot(accf) != 0ull) {
-      const RxColdParams cq = cold_params();
-      RxParams lp{};  // the fields emit_events reads
-      lp.ev_count = cq->ev_count; lp.events = cq->events; lp.events_cap = cq->events_cap; lp.stream_base = cq->stream_base;
-      lp.k_base = cq->k_base; lp.match_count = cq->match_count; lp.match_count_total = cq->match_count_total; lp.size = cq->size;
-      uint32_t dummy = 0;
-      emit_events(lp, accf != 0u, e, stream0 + sid, k, lane, dummy);
-      if (accf) atomicOr(region(sbo) + AM + ((k >> 5) & (L::AMW - 1u)), 1u << (k & 31u));
-    }
-  };
-
-  // One byte-consuming pass.
-  auto pass = [&](const uint32_t k_) {
-    const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k_);  // (scalar, also for the compiler)
-    const uint32_t c = cw_lo & 0xFFu, cn7 = (cw_lo >> 8) & 7u;
-    const bool look = k + 1u < n_consume;  // the next byte is consumed too (the set after the last byte is reported: no pruning)
-    pulses(k);
-    // {fast word, target word} of this lane's state on its stream's byte; free lanes and accept states read empty rows
-    const uint2 x = *reinterpret_cast<const uint2*>(resx + ((__umul24(e, ncls) + c) << 3));
-    // what the folded state of the stream this lane owns emits on the byte (already reduced to what survives the next one)
-    uint32_t vA = 0u;
-    if (k >= 1u) {
-      if (own) vA = pintab[(ow_lo & 0xFFu) * pin_cols + (look ? (ow_lo >> 8) & 0xFFu : ncls)];
-    }
-    // the windows move on by one byte
-    cw_lo = (cw_lo >> 8) | (cw_hi << 24);
-    cw_hi >>= 8;
-    ow_lo = (ow_lo >> 8) | (ow_hi << 24);
-    ow_hi >>= 8;
-    const uint32_t e_in = e, sid_in = sid, xf = x.x, xs = x.y;  // S_k: what the lanes hold when the pass begins
-    e = xf & 0xFFFFu;
-    static_assert(RXR_ACC == (1u << 30) && RXR_NEED == (1u << 31) && RXR_OVFL == (1u << 27), "flag positions used as shift counts");
-    static_assert(RXE_INLINE == (1u << 31) && RXE_OVF == (1u << 28) && RXE_PIN == (1u << 27), "flag positions used as shift counts");
-    accf = (xf >> 30) & 1u;
-    const uint32_t need = look ? (xf >> (16u + cn7)) & 1u : xf >> 31;
-    // a member of D leaves its lane: its bit goes
-    if (dbit != 0u && e != e_in) {
-#ifdef RX_RES_DEBUG
-      if (wave == 4u && k <= 3u) printf("[res] pass %u lane %u slot %u: state %u leaves, clears bit %08x at %u\n", k, lane, sid, e_in, dbit, dwa);
-#endif
-      atomicAnd(region(dwa), ~dbit);
-      dbit = 0u;
-    }
-    const uint32_t ovfl = (xf >> 27) & 1u;
-    uint32_t cA = need & (ovfl ^ 1u);  // one target (xs) wants a lane
-    uint32_t lA = need & ovfl;         // several do (list at res_ovf[xs & 0xFFFFFF])
-    uint32_t cB = (vA >> 31) & (((vA >> 27) & 1u) ^ 1u);
-    uint32_t lB = (vA >> 28) & 1u;
-    // candidates in D: one test-and-set each on the bit of (stream, state)
-    {
-      const uint32_t dA = (xs >> 16) & 0x3FFu, dB = (vA >> 16) & 0x3FFu;
-      uint32_t oA = 0u, oB = 0u;
-      if (cA != 0u && dA != 0u) oA = atomicOr(region(sbo + ((dA >> 5) << 2)), 1u << (dA & 31u));
-      if (cB != 0u && dB != 0u) oB = atomicOr(region(own_sbo + ((dB >> 5) << 2)), 1u << (dB & 31u));
-#ifdef RX_RES_DEBUG
-      if (wave == 4u && k <= 3u && cA != 0u) printf("[res] pass %u lane %u slot %u: candidate A state %u d %u old %08x (from state %u)\n", k, lane, sid, xs & 0xFFFFu, dA, oA, e_in);
-      if (wave == 4u && k <= 3u && cB != 0u) printf("[res] pass %u lane %u slot %u: candidate B state %u d %u old %08x\n", k, lane, own_slot, vA & 0xFFFFu, dB, oB);
-#endif
-      cA &= ((oA >> (dA & 31u)) & 1u) ^ 1u;
-      cB &= ((oB >> (dB & 31u)) & 1u) ^ 1u;
-    }
-    uint32_t lj = 0u;  // list sources: the next target of the list (an eviction interrupts the walk)
-
-    // The stream that holds the most lanes (entries after the update + what it wants to place) leaves: S_k and k to the
-    // hand-off area, its lanes free, its candidates dropped.  Wave-uniform call.
-    auto evict_one = [&]() {
-      const RxColdParams cq = cold_params();
-      // (what this code derives from the pass's values is computed HERE: without the barriers the compiler hoists it out of
-      // the placement loop, i.e. into every pass)
-      uint32_t kc = k, ei = e_in, si = sid_in;
-      asm volatile("" : "+s"(kc), "+v"(ei), "+v"(si));
-      wave_sync();
-      if (lane < (uint32_t)S) slotw[lane] = 0u;
-      wave_sync();
-      {
-        const uint32_t mine = (e != FREE ? 1u : 0u) + cA + 4u * lA, owned = cB + 4u * lB;
-        if (mine) atomicAdd(&slotw[sid], mine);
-        if (owned) atomicAdd(&slotw[own_slot], owned);
-      }
-      wave_sync();
-      uint32_t key = (own != 0u && lane < (uint32_t)S) ? ((slotw[lane] + 1u) << 6) | (63u - lane) : 0u;  // > 0 for every live slot
-      for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)key, d);
-        key = o > key ? o : key;
-      }
-      const uint32_t best = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
-      if (best == 0u) { spilled = 1u; return; }  // (cannot happen: an overflow has live streams)
-      const uint32_t v = 63u - (best & 63u);
-#ifdef RX_RES_DEBUG
-      if (lane == 0) printf("[res] wave %u pass %u: stream slot %u leaves (%u lanes + wishes)\n", wave, kc, v, (best >> 6) - 1u);
-      if (ei != FREE && si == v) printf("[res]   S_k member: lane %u state %u\n", lane, ei);
-#endif
-      unsigned long long b = 0;
-      if (lane == 0) b = atomicAdd(cq->spill_count, 1ull);
-      const uint32_t slot = bcast((uint32_t)b, 0);
-      uint32_t* row = cq->spill_rows + (size_t)slot * cq->nw64x2;
-      for (uint32_t w = lane; w < cq->nw64x2; w += 64u) row[w] = 0u;
-      if (lane == v) {
-        cq->spill_streams[slot] = stream0 + v;
-        cq->spill_k[slot] = kc;
-        if (cq->anymatch) {  // the words of the current 256-pass group up to the one of pass k (the wave kernel reads that one back)
-          const uint32_t* am = sreg0 + v * STRIDE + AM;
-          uint32_t* dst = cq->anymatch + (size_t)(stream0 + v) * cq->anymatch_stride + ((kc >> 8) << 3);
-          for (uint32_t w = 0; w <= ((kc >> 5) & (L::AMW - 1u)); w++) dst[w] = am[w];
-        }
-      }
-      __threadfence();
-      wave_sync();
-      // S_k of the leaving stream: what its lanes held when the pass began (sid_in: a lane whose state died in this pass may
-      // have been given to another stream's target since), plus the folded state from pass 1 on
-      if (ei != FREE && si == v) atomicOr(&row[ei >> 5], 1u << (ei & 31u));
-      if (kc >= 1u && lane == 0) atomicOr(&row[cq->pin_state >> 5], 1u << (cq->pin_state & 31u));
-      if (sid == v) {
-        if (e != FREE) { e = FREE; accf = 0u; }
-        dbit = 0u;
-        cA = 0u;
-        if (lA) lj = 0u;  // (an interrupted walk that is cancelled must not leave its position behind for the lane's next list)
-        lA = 0u;
-      }
-      if (lane == v) {
-        if (lB) lj = 0u;
-        cB = 0u;
-        lB = 0u;
-        own = 0u;
-      }
-      for (uint32_t w = lane; w < DW; w += 64u) sreg0[v * STRIDE + w] = 0u;
-      alive &= ~(1ull << v);
-      if (alive == 0ull) spilled = 1u;
-      wave_sync();
-    };
-
-    // Rows with several targets and emission lists: one target at a time into the first free lane (rare on snort_16).
-    // Returns 1 when it ran out of free lanes (the caller evicts a stream and comes back).  Wave-uniform call.
-    auto place_lists = [&]() -> uint32_t {
-      const RxColdParams cq = cold_params();
-      const uint32_t* __restrict__ rovf = cq->res_ovf;
-      for (uint32_t kind = 0; kind < 2u; kind++) {
-        // (the pending flags are balloted afresh for every list: an eviction cancels the lists of the stream that leaves, and a
-        // lane whose list was cancelled may since hold another stream's entry)
-        for (uint64_t ml; (ml = wballot(kind == 0u ? lA : lB)) != 0ull;) {
-          const uint32_t src = (uint32_t)__builtin_ctzll(ml);
-          const uint32_t tsid = kind == 0u ? bcast(sid, src) : src;
-          const uint32_t off = bcast(kind == 0u ? xs : vA, src) & RXE_TGT_MASK;
-          // (the classes the new lanes need are those of the NEXT bytes: the windows have moved on already)
-          const uint32_t lo = bcast(kind == 0u ? cw_lo : ow_lo, src), hi = bcast(kind == 0u ? cw_hi : ow_hi, src);
-          // (readfirstlane: the loads have wave-uniform addresses, and the compiler must know the results to be uniform too —
-          // otherwise this walk, its early return and with it the whole placement loop become lane-masked control flow)
-          const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)rovf[off]);
-          for (uint32_t j = bcast(lj, src); j < cnt; j++) {
-            const uint32_t tw = (uint32_t)__builtin_amdgcn_readfirstlane((int)rovf[off + 1u + j]);
-            if (tw & RXE_PIN) continue;
-            // (lanes whose own candidate or list is still pending keep their stream slot and classes until it is placed)
-            const uint64_t mfree = wballot(e == FREE && (cA | lA) == 0u);
-            if (mfree == 0ull) {
-              if (lane == src) lj = j;
-              return 1u;
-            }
-            const uint32_t d = (tw >> 16) & 0x3FFu;
-            if (d != 0u) {
-              uint32_t old = 0u;
-              if (lane == 0) old = atomicOr(&sreg0[tsid * STRIDE + (d >> 5)], 1u << (d & 31u));
-              if ((bcast(old, 0) >> (d & 31u)) & 1u) continue;  // already in the set
-            }
-            const uint32_t dst = (uint32_t)__builtin_ctzll(mfree);
-#ifdef RX_RES_DEBUG
-            if (wave == 4u && k <= 3u && lane == 0) printf("[res] pass %u: list target state %u of slot %u (d %u) into lane %u\n", k, tw & 0xFFFFu, tsid, d, dst);
-#endif
-            if (lane == dst) {
-              e = tw & 0xFFFFu;
-              accf = (tw >> 30) & 1u;
-              sid = tsid;
-              sbo = tsid * STRIDE4;
-              cw_lo = lo;
-              cw_hi = hi;
-              dbit = d != 0u ? 1u << (d & 31u) : 0u;
-              dwa = tsid * STRIDE4 + ((d >> 5) << 2);
-            }
-          }
-          if (lane == src) {  // this list is placed
-            if (kind == 0u) lA = 0u;
-            else lB = 0u;
-            lj = 0u;
-          }
-        }
-      }
-      return 0u;
-    };
-
-    uint64_t mA, mB, mf;
-    uint32_t nA, nB;
-    for (;;) {
-      uint32_t full = 0u;
-      if (__builtin_expect(wballot(lA | lB) != 0ull, 0)) full = (uint32_t)__builtin_amdgcn_readfirstlane((int)place_lists());
-      mA = wballot(cA);
-      mB = wballot(cB);
-      mf = wballot(e == FREE);
-      nA = (uint32_t)__popcll(mA);
-      nB = (uint32_t)__popcll(mB);
-      if (__builtin_expect(full == 0u && nA + nB <= (uint32_t)__popcll(mf), 1)) break;
-      evict_one();
-      if (__builtin_amdgcn_readfirstlane((int)spilled)) return;
-    }
-    // the single candidates: ranked, through the scratch line, into the free lanes ranked the same way
-    if (nA + nB != 0u) {
-      uint4* scr4 = reinterpret_cast<uint4*>(scr);
-      if (cA) scr4[rank_below(mA)] = make_uint4(xs, sid, cw_lo, cw_hi);
-      if (cB) scr4[rank_below_plus(mB, nA)] = make_uint4(vA, own_slot, ow_lo, ow_hi);
-      wave_sync();
-      const uint32_t rf = rank_below(mf);
-      if (e == FREE && rf < nA + nB) {
-        const uint4 t = scr4[rf];
-        const uint32_t d = (t.x >> 16) & 0x3FFu;
-#ifdef RX_RES_DEBUG
-        if (wave == 4u && k <= 3u) printf("[res] pass %u: lane %u takes state %u of slot %u (d %u)\n", k, lane, t.x & 0xFFFFu, t.y, d);
-#endif
-        e = t.x & 0xFFFFu;
-        accf = (t.x >> 30) & 1u;
-        sid = t.y;
-        sbo = t.y * STRIDE4;
-        cw_lo = t.z;
-        cw_hi = t.w;
-        dbit = d != 0u ? 1u << (d & 31u) : 0u;
-        dwa = sbo + ((d >> 5) << 2);
-      }
-      wave_sync();
-    }
-  };
-
-  uint32_t k = 0;
-  while (k < n_consume && !spilled) {  // k is a multiple of 64 here
-    refill(k);
-    const uint32_t kend = n_consume - k < 64u ? n_consume : k + 64u;
-    while (k < kend && !spilled) {  // k is a multiple of 4 here: the classes of the next eight bytes of every lane's stream
-      const uint32_t kk = k & 63u;
-      {
-        const uint32_t* w = region(sbo + WIN4 + kk);
-        cw_lo = w[0];
-        cw_hi = w[1];
-        const uint32_t* o = region(own_sbo + WIN4 + kk);
-        ow_lo = o[0];
-        ow_hi = o[1];
-      }
-      const uint32_t k4 = kend - k < 4u ? kend : k + 4u;
-      do {
-        pass(k);
-        k = (uint32_t)__builtin_amdgcn_readfirstlane((int)(k + 1u));
-      } while (k < k4 && !spilled);
-      if (!spilled && (k & 255u) == 0u) store_anymatch((k >> 8) - 1u);
-      if ((k & 63u) == 32u) stash_next_first();
-    }
-  }
-  while (k < p.n_passes && !spilled) {  // RX_MODE_FULL: pass N only looks for accept states
-    pulses(k);
-    k++;
-    if ((k & 255u) == 0u) store_anymatch((k >> 8) - 1u);
-  }
-  if (!spilled && (k & 255u) != 0u) store_anymatch(k >> 8);
-  // final active sets of the streams that stayed: the lanes' entries as a list, then as the pack kernel stores them
-  if (!spilled) {
-    wave_sync();
-    const uint64_t m = wballot(e != FREE);
-    if (e != FREE) clw[rank_below(m)] = e | (sid << SID_SHIFT);
-    wave_sync();
-    pack_store_final_sets<S, L::SCRW, SID_BITS>(clw, scr, slotw, (uint32_t)__popcll(m), lane, own != 0u, alive, n_mine, stream0, n_consume >= 1u);
   }
 }
 
@@ -2628,7 +2189,7 @@ int rx_pick_launch(uint32_t kernel, uint32_t size, uint32_t n_streams, int cu_co
   cfg->lds_per_cu = lds_per_cu;
   if (kernel == RX_KERNEL_AUTO) kernel = RX_KERNEL_SYM_PACK;  // fastest parity-checked kernel
   if (kernel != RX_KERNEL_CSR_WAVE && kernel != RX_KERNEL_SYM_WAVE && kernel != RX_KERNEL_SYM_GROUP &&
-      kernel != RX_KERNEL_SYM_PACK && kernel != RX_KERNEL_DFA && kernel != RX_KERNEL_SYM_REG && kernel != RX_KERNEL_SYM_RES)
+      kernel != RX_KERNEL_SYM_PACK && kernel != RX_KERNEL_DFA && kernel != RX_KERNEL_SYM_REG)
     return RX_EINVAL;
   const uint32_t nw32 = (size + 31u) / 32u;
   p->nw32 = nw32;
@@ -2653,7 +2214,6 @@ int rx_pick_launch(uint32_t kernel, uint32_t size, uint32_t n_streams, int cu_co
     const uint32_t gl = cfg->group_lanes;
     if (gl != 1 && gl != 2 && gl != 4 && gl != 8 && gl != 16) cfg->group_lanes = 4;
   }
-  if (kernel == RX_KERNEL_SYM_RES && cfg->group_lanes == 0) cfg->group_lanes = 16;  // streams per wavefront
   return RX_OK;
 }
 
@@ -2736,29 +2296,6 @@ static int launch_fold(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s,
   return launch_one(rx_sym_pack_kernel<S, false, false, false, true>, p, g, wpb * 64u, lds, s);
 }
 
-// resident-entry kernel: the block shares one copy of the folding table; up to 8 wavefronts per block
-template <int S>
-static int launch_res(const RxParams& p, const RxLaunchCfg& cfg, hipStream_t s, size_t lds_per_cu) {
-  using L = ResLayout<S>;
-  const uint32_t ww = L::wave_words((p.res_dwords + 1u) & ~1u);
-  const uint32_t fixed = L::CMAPW + ((p.n_classes * p.pin_cols + 3u) & ~3u);
-  const uint32_t waves = (p.n_streams + S - 1) / S;
-  uint32_t wpb = 0, best_rounds = ~0u, best_load = ~0u;
-  const uint32_t cus = cfg.cu_count > 0 ? (uint32_t)cfg.cu_count : 256u;
-  for (uint32_t w = 1; w <= 8; w++) {  // fewest rounds of resident blocks per CU, then the fewest wavefronts on the busiest CU
-    const size_t bytes = (size_t)(fixed + w * ww) * 4u;
-    if (bytes > lds_per_cu || bytes > 65536u * 2u) break;
-    const uint32_t resident = (uint32_t)std::min<size_t>(lds_per_cu / bytes, 32u / w);
-    const uint32_t blocks = (waves + w - 1) / w;
-    const uint32_t per_cu = (blocks + cus - 1) / cus;
-    const uint32_t rounds = (per_cu + resident - 1) / resident, load = per_cu * w;
-    if (rounds < best_rounds || (rounds == best_rounds && load <= best_load)) { best_rounds = rounds; best_load = load; wpb = w; }
-  }
-  if (wpb == 0) return (int)hipErrorInvalidValue;
-  const uint32_t grid = (waves + wpb - 1) / wpb;
-  return launch_one(rx_sym_res_kernel<S>, p, grid ? grid : 1, wpb * 64u, (fixed + wpb * ww) * 4u, s);
-}
-
 // returns a hipError_t value (0 = hipSuccess)
 int rx_launch(const RxParams& p, const RxLaunchCfg& cfg, void* hip_stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
@@ -2772,20 +2309,10 @@ int rx_launch(const RxParams& p, const RxLaunchCfg& cfg, void* hip_stream) {
                        : launch_one(rx_sym_wave_kernel<false>, p, cfg.grid_blocks, cfg.block_threads, cfg.lds_bytes, s);
     case RX_KERNEL_DFA:
     case RX_KERNEL_SYM_REG:
-    case RX_KERNEL_SYM_RES:
     case RX_KERNEL_SYM_PACK:
     case RX_KERNEL_SYM_GROUP: {
       int e;
-      if (cfg.kernel == RX_KERNEL_SYM_RES) {
-        if (!p.res_idx || !p.res_pin || !p.res_ovf || p.res_dwords == 0u || p.res_dwords > 32u) return (int)hipErrorInvalidValue;
-        const size_t lds_cu = cfg.lds_per_cu ? cfg.lds_per_cu : 160u * 1024u;
-        const uint32_t gl = cfg.group_lanes;  // nearest instantiated number of streams per wavefront
-        if (gl <= 8) e = launch_res<8>(p, cfg, s, lds_cu);
-        else if (gl <= 16) e = launch_res<16>(p, cfg, s, lds_cu);
-        else if (gl <= 24) e = launch_res<24>(p, cfg, s, lds_cu);
-        else if (gl <= 32) e = launch_res<32>(p, cfg, s, lds_cu);
-        else e = launch_res<48>(p, cfg, s, lds_cu);
-      } else if (cfg.kernel == RX_KERNEL_SYM_REG) {  // one wavefront (= one block) per stream
+      if (cfg.kernel == RX_KERNEL_SYM_REG) {  // one wavefront (= one block) per stream
         const bool fold = cfg.fold && p.pin_tab;
         const uint32_t lds = 64u * 4u;  // the byte -> class map; the folding table is read with scalar loads
         if (cfg.reg_skip)

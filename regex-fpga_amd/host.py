@@ -13,8 +13,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 MODE_FULL, MODE_TB_COMPAT = 0, 1
-KERNEL_AUTO, KERNEL_CSR_WAVE, KERNEL_SYM_WAVE, KERNEL_SYM_GROUP, KERNEL_SYM_PACK, KERNEL_DFA, KERNEL_SYM_REG, KERNEL_SYM_RES = 0, 1, 2, 3, 4, 5, 6, 7
-KERNEL_NAMES = {0: "auto", 1: "csr_wave", 2: "sym_wave", 3: "sym_group", 4: "sym_pack", 5: "dfa", 6: "sym_reg", 7: "sym_res"}
+KERNEL_AUTO, KERNEL_CSR_WAVE, KERNEL_SYM_WAVE, KERNEL_SYM_GROUP, KERNEL_SYM_PACK, KERNEL_DFA, KERNEL_SYM_REG = 0, 1, 2, 3, 4, 5, 6
+KERNEL_NAMES = {0: "auto", 1: "csr_wave", 2: "sym_wave", 3: "sym_group", 4: "sym_pack", 5: "dfa", 6: "sym_reg"}
 
 # rx_opts.flags (A/B and diagnostic switches; read at plan creation, never from the environment)
 OPT_NO_PRUNE, OPT_FORCE_PRUNE, OPT_VERBOSE, OPT_PROFILE_PACK, OPT_NO_FOLD, OPT_FORCE_FOLD, OPT_REG_NO_SKIP = 1, 2, 4, 8, 16, 32, 64

@@ -34,11 +34,7 @@ def kernels(rx):
             dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=64, flags=rx.host.OPT_FORCE_FOLD),
             # register-resident one-wavefront-per-stream kernel, folded (default) and unfolded, with and without stepping over idle passes
             dict(kernel=rx.KERNEL_SYM_REG), dict(kernel=rx.KERNEL_SYM_REG, flags=rx.host.OPT_NO_FOLD),
-            dict(kernel=rx.KERNEL_SYM_REG, flags=rx.host.OPT_REG_NO_SKIP), dict(kernel=rx.KERNEL_SYM_REG, flags=rx.host.OPT_REG_NO_SKIP | rx.host.OPT_NO_FOLD),
-            # resident entries: S streams per wavefront, one (stream, state) entry per lane (wave kernel on automata that do not qualify)
-            dict(kernel=rx.KERNEL_SYM_RES, group_lanes=8), dict(kernel=rx.KERNEL_SYM_RES, group_lanes=16),
-            dict(kernel=rx.KERNEL_SYM_RES, group_lanes=24), dict(kernel=rx.KERNEL_SYM_RES, group_lanes=32),
-            dict(kernel=rx.KERNEL_SYM_RES, group_lanes=48)]
+            dict(kernel=rx.KERNEL_SYM_REG, flags=rx.host.OPT_REG_NO_SKIP), dict(kernel=rx.KERNEL_SYM_REG, flags=rx.host.OPT_REG_NO_SKIP | rx.host.OPT_NO_FOLD)]
 
 
 @pytest.fixture(scope="module")

@@ -21,7 +21,6 @@ rx = importlib.import_module("regex-fpga_amd")
 KERNELS = [dict(kernel=rx.KERNEL_CSR_WAVE), dict(kernel=rx.KERNEL_SYM_WAVE)] + \
           [dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=g) for g in (1, 2, 4, 8, 16)] + \
           [dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=s) for s in (2, 4, 8, 11, 12, 13, 16, 20, 22, 24, 32, 48, 64)] + \
-          [dict(kernel=rx.KERNEL_SYM_RES, group_lanes=s) for s in (8, 16, 24, 32, 48)] + \
           [dict(kernel=rx.KERNEL_SYM_REG), dict(kernel=rx.KERNEL_SYM_REG), dict(kernel=rx.KERNEL_DFA), dict(kernel=rx.KERNEL_AUTO)]
 
 
