@@ -152,6 +152,7 @@ struct StreamState {
   uint32_t* clist;  // current active list (valid when !dense)
   uint32_t* nlist;
   uint32_t n_cur, n_next;
+  uint32_t cap;     // entries a list holds (RxParams::lds_words_per_stream minus the two bitmasks, halved)
   bool dense;
 };
 
@@ -168,7 +169,7 @@ __device__ __forceinline__ void emit_target(StreamState& st, bool pred, uint32_t
   const uint64_t m = wballot(fresh);
   if (m) {
     const uint32_t slot = st.n_next + rank_below(m);
-    if (fresh && slot < RX_LIST_CAP) st.nlist[slot] = t;
+    if (fresh && slot < st.cap) st.nlist[slot] = t;
     st.n_next += (uint32_t)__popcll(m);
   }
 }
@@ -178,7 +179,8 @@ __device__ __forceinline__ void stream_reset(const RxParams& p, StreamState& st,
   st.cb = my;
   st.nb = my + p.nw32;
   st.clist = st.nb + p.nw32;
-  st.nlist = st.clist + RX_LIST_CAP;
+  st.cap = (p.lds_words_per_stream - 2u * p.nw32) >> 1;
+  st.nlist = st.clist + st.cap;
   for (uint32_t w = lane; w < 2u * p.nw32; w += 64u) my[w] = 0u;
   st.n_next = 0;
   if (init_row) {  // chunked streaming / spill hand-off: resume from a given active set
@@ -199,7 +201,7 @@ __device__ __forceinline__ void stream_swap(const RxParams& p, StreamState& st, 
   wave_sync();
   if (st.dense)
     for (uint32_t w = lane; w < p.nw32; w += 64u) st.cb[w] = 0u;
-  if (st.n_next > RX_LIST_CAP) {  // list overflowed: the bitmask is the set
+  if (st.n_next > st.cap) {  // list overflowed: the bitmask is the set
     uint32_t* t = st.cb; st.cb = st.nb; st.nb = t;
     st.dense = true;
     st.n_cur = 0;
@@ -2194,7 +2196,14 @@ int rx_pick_launch(uint32_t kernel, uint32_t size, uint32_t n_streams, int cu_co
   const uint32_t nw32 = (size + 31u) / 32u;
   p->nw32 = nw32;
   // wave-per-stream carve (also used by the resume launch that follows a group launch)
-  p->lds_words_per_stream = 2u * nw32 + 2u * RX_LIST_CAP;
+  // Lists as long as the LDS allows, up to RX_LIST_CAP_MAX entries: a set that outgrows its list is walked as a bitmask, one
+  // 32-state word at a time — 222 active states of snort_16 are ~150 nearly empty words per pass against four full sweeps of
+  // a list (the streams the pack kernel hands off are exactly such streams: bench.py handoff_mix_T)
+  // (a batch that runs on the wave kernels as a whole keeps eight wavefronts per SIMD resident: 256 entries; the launch that
+  // only finishes hand-offs has few streams and takes the long lists)
+  uint32_t cap = (kernel == RX_KERNEL_CSR_WAVE || kernel == RX_KERNEL_SYM_WAVE) ? 256u : RX_LIST_CAP_MAX;
+  while (cap > RX_LIST_CAP && (size_t)(2u * nw32 + 2u * cap) * 4u * 4u > lds_per_cu / 2) cap >>= 1;
+  p->lds_words_per_stream = 2u * nw32 + 2u * cap;
   const size_t per_wave = (size_t)p->lds_words_per_stream * 4u;
   if (per_wave > lds_per_cu) return RX_ECAPACITY;  // automaton too large for an LDS-resident bitmask
   uint32_t wpb = 4;
