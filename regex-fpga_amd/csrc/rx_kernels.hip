@@ -933,7 +933,7 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
   const uint32_t n_mine_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_mine);
   unsigned long long alive = n_mine_s >= 64u ? ~0ull : (1ull << n_mine_s) - 1ull;
   bool owner = lane < n_mine;  // lane == stream slot it owns (and still handles)
-  uint32_t replay = 0u;        // 1: the pass is being run again after an eviction (its accept pulses are out already); scalar
+  bool overflow = false;       // the pass that just ran could not hold its next sets: a stream has to leave (scalar; see `evict`)
   // input windows: lane = 4*slot + part fetches bytes [64*chunk + 16*part, +16) of stream `slot`
   static_assert(S >= 1 && S <= (FOLD ? 64 : 32), "five-bit (FOLD: six-bit) stream slot; the window loader covers 16 streams per wave-load");
   constexpr uint32_t NLOAD = (S + 15) / 16;  // wave-loads per refill
@@ -1074,8 +1074,10 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
   // One pass (FPGA.v:158-741 for S streams).  `consume` is a compile-time tag: the passes that take an input byte are
   // driven by the chunked loops below (no per-pass refill / bitmap / mode tests); FULL mode's pass N only looks for
   // accept states.
-  auto pass = [&](const uint32_t k, auto consume_tag) {
+  // `replay_tag`: the pass is being run again after an eviction — its accept pulses (and statistics) are out already.
+  auto pass = [&](const uint32_t k, auto consume_tag, auto replay_tag) {
     constexpr bool consume = decltype(consume_tag)::value;
+    constexpr bool replay = decltype(replay_tag)::value;
     const uint32_t kk = k & 63u;
     stamp(-1);
     Nn = 0;
@@ -1328,95 +1330,99 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
     stamp(5);  // phase 5: overflow lists + loop control
     if (consume) {
       if (__builtin_expect(Nn > L::CAPW, 0)) {
-        // The wave-wide list cannot hold the next sets.  The streams with the most entries in the part of the next list that
-        // was written leave — one if that brings the written part under 5/8 of the capacity (a single stream that explodes),
-        // more if the load is spread (then one at a time would overflow again a few passes on) — each with its S_k (its
-        // entries of the current list, still intact) and k, to be finished by the wave kernel; their slots go idle.  The other
-        // streams run this pass again (replay: their accept pulses of pass k are out already, as are the leaving streams',
-        // which the wave kernel therefore skips at k).
-        const RxColdParams cq = cold_params();
-        wave_sync();
-        uint32_t c_next = 0;
-        const uint32_t lim = Nn < L::CAPW ? Nn : L::CAPW;
-        for (uint32_t q = 0; q < lim; q++) c_next += ((nlist[q] >> SID_SHIFT) & SID_BITS) == lane ? 1u : 0u;
-        unsigned long long victims = 0ull;  // (scalar)
-        uint32_t left = lim;
-        do {
-          // most entries, lowest slot on ties; > 0 for every live slot that has not been picked yet
-          uint32_t key = (owner && ((victims >> lane) & 1ull) == 0ull) ? ((c_next + 1u) << 6) | (63u - lane) : 0u;
-          for (int d = 32; d >= 1; d >>= 1) {
-            const uint32_t o = (uint32_t)__shfl_xor((int)key, d);
-            key = o > key ? o : key;
-          }
-          // (every lane holds the maximum; through an SGPR so that everything derived from it — the set of live slots, the
-          // loop conditions — stays scalar for the compiler too)
-          const uint32_t best = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
-          if (best == 0u) break;
-          victims |= 1ull << (63u - (best & 63u));
-          left -= (best >> 6) - 1u;
-        } while (left > (L::CAPW * 5u) / 8u);
-        const uint32_t n_vict = (uint32_t)__popcll(victims);
-        unsigned long long b = 0;
-        if (lane == 0) b = atomicAdd(cq->spill_count, (unsigned long long)n_vict);
-        const uint32_t slot_base = bcast((uint32_t)b, 0);
-        const bool i_leave = ((victims >> lane) & 1ull) != 0ull;  // (lane == stream slot)
-        const uint32_t my_slot = slot_base + (uint32_t)__popcll(victims & ((1ull << lane) - 1ull));
-        if (lane < (uint32_t)S) slotw[lane] = my_slot;
-        {
-          uint32_t* rows = cq->spill_rows + (size_t)slot_base * cq->nw64x2;
-          for (uint32_t w = lane; w < n_vict * cq->nw64x2; w += 64u) rows[w] = 0u;
-        }
-        if (i_leave) {
-          cq->spill_streams[my_slot] = stream0 + lane;
-          cq->spill_k[my_slot] = k;
-          if (cq->anymatch) {  // the words of the current 256-pass group up to the one of pass k (which the wave kernel reads back)
-            const uint32_t* am = sreg0 + lane * L::STRIDE + 2u * L::FW + L::WINW;
-            uint32_t* dst = cq->anymatch + (size_t)(stream0 + lane) * cq->anymatch_stride + ((k >> 8) << 3);
-            for (uint32_t w = 0; w <= ((k >> 5) & (L::AMW - 1u)); w++) dst[w] = am[w];
-          }
-        }
-        __threadfence();
-        wave_sync();
-        // S_k of the leaving streams into their hand-off rows; the list without them into the other buffer
-        uint32_t M = 0;
-        for (uint32_t b0 = 0; b0 < N; b0 += 64u) {
-          const uint32_t li = b0 + lane;
-          const uint32_t e = li < N ? clist[li] : 0u;
-          const uint32_t es = (e >> SID_SHIFT) & SID_BITS;
-          const bool goes = li < N && ((victims >> es) & 1ull) != 0ull;
-          if (goes) {
-            const uint32_t sq = e & RXE_TGT_MASK;
-            atomicOr(&cq->spill_rows[(size_t)slotw[es] * cq->nw64x2 + (sq >> 5)], 1u << (sq & 31u));
-          }
-          const bool keep = li < N && !goes;
-          const uint64_t mk = wballot(keep);
-          if (keep) nlist[rank_below_plus(mk, M)] = e;
-          M += (uint32_t)__popcll(mk);
-        }
-        if (FOLD && k >= 1u && i_leave)  // S_k holds the folded state
-          atomicOr(&cq->spill_rows[(size_t)my_slot * cq->nw64x2 + (cq->pin_state >> 5)], 1u << (cq->pin_state & 31u));
-        {
-          uint32_t* t = clist; clist = nlist; nlist = t;
-        }
-        N = M;
-        // both filters of every slot start clean (bits of entries that were counted but not written would otherwise stay)
-        for (uint32_t w = lane; w < (uint32_t)S * 2u * L::FW; w += 64u) sreg0[(w / (2u * L::FW)) * L::STRIDE + (w % (2u * L::FW))] = 0u;
-        alive &= ~victims;
-        owner = lane < n_mine && ((alive >> lane) & 1ull) != 0ull;
-        replay = 1u;
-        if (alive == 0ull) spilled = true;  // nothing left here
-        wave_sync();
+        overflow = true;  // (handled by the caller, outside the loop of passes: `evict`, then this pass again)
       } else {
         {  // current <- next (FPGA.v:733-737)
           uint32_t* t = clist; clist = nlist; nlist = t;
           const uint32_t f = fcur_b; fcur_b = fnext_b; fnext_b = f;
         }
         N = Nn;
-        replay = 0u;
         wave_sync();
       }
     }
     stamp(6);  // phase 6: end of pass (swap, wave sync)
+  };
+
+  // Called when a pass has left `overflow` set (wave-uniform; kept out of the loop of passes — inside the pass it cost every
+  // pass of every workload 1.8 %: same-box build without it, tools/r3_ab8.sh).
+  auto evict = [&](const uint32_t k) {
+    // The wave-wide list cannot hold the next sets.  The streams with the most entries in the part of the next list that
+    // was written leave — one if that brings the written part under 5/8 of the capacity (a single stream that explodes),
+    // more if the load is spread (then one at a time would overflow again a few passes on) — each with its S_k (its
+    // entries of the current list, still intact) and k, to be finished by the wave kernel; their slots go idle.  The other
+    // streams run this pass again (replay: their accept pulses of pass k are out already, as are the leaving streams',
+    // which the wave kernel therefore skips at k).
+    const RxColdParams cq = cold_params();
+    wave_sync();
+    uint32_t c_next = 0;
+    const uint32_t lim = Nn < L::CAPW ? Nn : L::CAPW;
+    for (uint32_t q = 0; q < lim; q++) c_next += ((nlist[q] >> SID_SHIFT) & SID_BITS) == lane ? 1u : 0u;
+    unsigned long long victims = 0ull;  // (scalar)
+    uint32_t left = lim;
+    do {
+      // most entries, lowest slot on ties; > 0 for every live slot that has not been picked yet
+      uint32_t key = (owner && ((victims >> lane) & 1ull) == 0ull) ? ((c_next + 1u) << 6) | (63u - lane) : 0u;
+      for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)key, d);
+        key = o > key ? o : key;
+      }
+      // (every lane holds the maximum; through an SGPR so that everything derived from it — the set of live slots, the
+      // loop conditions — stays scalar for the compiler too)
+      const uint32_t best = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+      if (best == 0u) break;
+      victims |= 1ull << (63u - (best & 63u));
+      left -= (best >> 6) - 1u;
+    } while (left > (L::CAPW * 5u) / 8u);
+    const uint32_t n_vict = (uint32_t)__popcll(victims);
+    unsigned long long b = 0;
+    if (lane == 0) b = atomicAdd(cq->spill_count, (unsigned long long)n_vict);
+    const uint32_t slot_base = bcast((uint32_t)b, 0);
+    const bool i_leave = ((victims >> lane) & 1ull) != 0ull;  // (lane == stream slot)
+    const uint32_t my_slot = slot_base + (uint32_t)__popcll(victims & ((1ull << lane) - 1ull));
+    if (lane < (uint32_t)S) slotw[lane] = my_slot;
+    {
+      uint32_t* rows = cq->spill_rows + (size_t)slot_base * cq->nw64x2;
+      for (uint32_t w = lane; w < n_vict * cq->nw64x2; w += 64u) rows[w] = 0u;
+    }
+    if (i_leave) {
+      cq->spill_streams[my_slot] = stream0 + lane;
+      cq->spill_k[my_slot] = k;
+      if (cq->anymatch) {  // the words of the current 256-pass group up to the one of pass k (which the wave kernel reads back)
+        const uint32_t* am = sreg0 + lane * L::STRIDE + 2u * L::FW + L::WINW;
+        uint32_t* dst = cq->anymatch + (size_t)(stream0 + lane) * cq->anymatch_stride + ((k >> 8) << 3);
+        for (uint32_t w = 0; w <= ((k >> 5) & (L::AMW - 1u)); w++) dst[w] = am[w];
+      }
+    }
+    __threadfence();
+    wave_sync();
+    // S_k of the leaving streams into their hand-off rows; the list without them into the other buffer
+    uint32_t M = 0;
+    for (uint32_t b0 = 0; b0 < N; b0 += 64u) {
+      const uint32_t li = b0 + lane;
+      const uint32_t e = li < N ? clist[li] : 0u;
+      const uint32_t es = (e >> SID_SHIFT) & SID_BITS;
+      const bool goes = li < N && ((victims >> es) & 1ull) != 0ull;
+      if (goes) {
+        const uint32_t sq = e & RXE_TGT_MASK;
+        atomicOr(&cq->spill_rows[(size_t)slotw[es] * cq->nw64x2 + (sq >> 5)], 1u << (sq & 31u));
+      }
+      const bool keep = li < N && !goes;
+      const uint64_t mk = wballot(keep);
+      if (keep) nlist[rank_below_plus(mk, M)] = e;
+      M += (uint32_t)__popcll(mk);
+    }
+    if (FOLD && k >= 1u && i_leave)  // S_k holds the folded state
+      atomicOr(&cq->spill_rows[(size_t)my_slot * cq->nw64x2 + (cq->pin_state >> 5)], 1u << (cq->pin_state & 31u));
+    {
+      uint32_t* t = clist; clist = nlist; nlist = t;
+    }
+    N = M;
+    // both filters of every slot start clean (bits of entries that were counted but not written would otherwise stay)
+    for (uint32_t w = lane; w < (uint32_t)S * 2u * L::FW; w += 64u) sreg0[(w / (2u * L::FW)) * L::STRIDE + (w % (2u * L::FW))] = 0u;
+    alive &= ~victims;
+    owner = lane < n_mine && ((alive >> lane) & 1ull) != 0ull;
+    if (alive == 0ull) spilled = true;  // nothing left here
+    wave_sync();
   };
 
   uint32_t k = 0;
@@ -1434,19 +1440,26 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
           if ((rest & 1ull) == 0ull) {
             const uint32_t skip = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
             k += skip < k32 - k ? skip : k32 - k;
-            replay = 0u;  // (a pass to be run again after an eviction that is a no-op for the streams that stayed)
             continue;
           }
         }
-        pass(k, std::true_type{});
-        k += 1u - replay;  // (a stream was evicted: the same pass again for the others)
+        pass(k, std::true_type{}, std::false_type{});
+        while (__builtin_expect(overflow, 0)) {  // streams leave until the pass fits; it is run again for those that stay
+          overflow = false;
+          evict(k);
+          if (spilled) break;
+          // (FOLD: nothing left in the list and no folded state emits at k — the pass is a no-op for the streams that stayed)
+          if (FOLD && __builtin_amdgcn_readfirstlane((int)N) == 0 && ((busy >> (k & 63u)) & 1ull) == 0ull) break;
+          pass(k, std::true_type{}, std::true_type{});
+        }
+        k++;
       } while (k < k32 && !spilled);
       if (!spilled && p.anymatch && (k & 255u) == 0u) store_anymatch((k >> 8) - 1u);
       if (LOOK && (k & 63u) == 32u) stash_next_first();
     }
   }
   while (k < p.n_passes && !spilled) {  // RX_MODE_FULL: pass N
-    pass(k, std::false_type{});
+    pass(k, std::false_type{}, std::false_type{});
     k++;
     if (p.anymatch && (k & 255u) == 0u) store_anymatch((k >> 8) - 1u);
   }
