@@ -1128,7 +1128,7 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
     if (pin_now && owner) {
       const uint8_t* wb = reinterpret_cast<const uint8_t*>(sreg0 + lane * L::STRIDE + 2u * L::FW);
       const uint32_t c0 = wb[kk];
-      const uint32_t sel = (k + 1u < p.n_consume) ? (uint32_t)wb[kk + 1u] : ncls;  // byte 64 of the window: stash
+      const uint32_t sel = (k + 1u < p.n_consume) ? (uint32_t)wb[kk + 1u] : ncls_v;  // byte 64 of the window: stash
       vA = pintab[c0 * p.pin_cols + sel];
     }
     bool pin_done = !pin_now;
@@ -1278,9 +1278,12 @@ __global__ void __launch_bounds__(FOLD ? 512 : 256) rx_sym_pack_kernel(const RxP
         if (prune) {
           // directory entry for the class of the stream's next byte; the full list when the sets built now are the
           // ones reported (the stream's last byte)
-          uint32_t sel = ncls;
+          // (ncls_v, the copy in a VGPR: the scalar one does not survive this loop's register pressure — the compiler re-reads
+          // it from the kernel-argument segment, an s_load and its wait in every pass of every workload with multi-target rows:
+          // SQ_INSTS_SMEM 1e5 -> 5.9e6 per launch on the rule-set stand-in; taking it out did not move that launch's time, though)
+          uint32_t sel = ncls_v;
           if (k + 1u < p.n_consume) sel = reinterpret_cast<const uint8_t*>(sreg + 2u * L::FW)[kk + 1u];  // byte 64: stash
-          const uint32_t d = (x & RXE_OVF) ? p.ovf_dir[(x & xtmask) * (ncls + 1u) + sel] : 0u;
+          const uint32_t d = (x & RXE_OVF) ? p.ovf_dir[(x & xtmask) * (ncls_v + 1u) + sel] : 0u;
           myoff = d >> 8;
           mycnt = d & 255u;
           if (mycnt == 255u) mycnt = ovf[myoff];

@@ -266,20 +266,23 @@ def test_pass_indices_up_to_the_32_bit_limit(rx, orx, automata, traces, gpu_nfas
         assert e.value.code == -1
 
 
-def test_active_set_larger_than_list_capacity(rx, orx, kernels):
-    """|S_k| = 300 > RX_LIST_CAP: the dense (bitmask-walk) form must give identical results."""
-    W, size = blowup_nfa(300)
+@pytest.mark.parametrize("width", [300, 1300])
+def test_active_set_larger_than_list_capacity(rx, orx, kernels, width):
+    """|S_k| = 300 > the 256 entries a wave-kernel list holds when that kernel runs the batch (list form, 1 024 entries, in the
+    launch that finishes the other kernels' hand-offs), |S_k| = 1 300 > both: the dense (bitmask-walk) form and the list form
+    must give identical results."""
+    W, size = blowup_nfa(width)
     nfa = rx.Nfa.from_words(W)
     rng = np.random.default_rng(5)
     rows = rng.choice(np.array([0x41, 0x42, 0x43, 0x44], np.uint8), size=(9, 64), p=[0.45, 0.05, 0.45, 0.05])
     rows[0, :6] = [0x43, 0x41, 0x41, 0x43, 0x42, 0x43]
     ref = orx.match_batch(W, size, rows, want_match_count=True)
-    assert ref["stats"]["sum_active"] > 300 * 20 and ref["n_events"] >= 1
+    assert ref["stats"]["sum_active"] > width * 20 and ref["n_events"] >= 1 and ref["stats"]["max_active"] >= width
     for kern in kernels:
         got = rx.match(nfa, rows, **kern, want_match_count=True, collect_stats=True)
-        check_equal(rx, orx, got, ref, ("blowup", kern))
+        check_equal(rx, orx, got, ref, ("blowup", width, kern))
         got = rx.match(nfa, rows, **kern, want_match_count=True)
-        check_equal(rx, orx, got, ref, ("blowup", kern, "plain"), stats=False)
+        check_equal(rx, orx, got, ref, ("blowup", width, kern, "plain"), stats=False)
 
 
 def test_handoff_in_the_middle_of_a_stream(rx, orx, kernels):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""What the final sets cost the pack kernel on T: kernel time with bitmask rows / compact lists / none, any-match on / off."""
+"""What the final sets cost the pack kernel on T (or, with argument R, on the rule-set stand-in): kernel time with bitmask rows / compact lists / none, any-match on / off."""
 import importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,8 +10,13 @@ wl = rx.workloads
 W = orx.load_coe(wl.SNORT_COE); size = orx.infer_size(W)
 lo = orx.load_mem(wl.TRACES[("snort_16", "lo")]); hi = orx.load_mem(wl.TRACES[("snort_16", "hi")])
 ns, sl = 65536, 1024
-nfa = rx.Nfa.from_words(W, size)
-rows = wl.trace_windows(lo, hi, ns, sl)
+if len(sys.argv) > 1 and sys.argv[1] == "R":  # the rule-set stand-in instead of snort_16 / T
+    pats = wl.synthetic_ruleset()
+    nfa = rx.Nfa.compile(pats)
+    rows = wl.ruleset_traffic(pats, ns, sl, workers=8)
+else:
+    nfa = rx.Nfa.from_words(W, size)
+    rows = wl.trace_windows(lo, hi, ns, sl)
 d = torch.from_numpy(rows).to("cuda:0")
 for label, kw in (("rows + any-match", dict(want_final=True, want_anymatch=True)), ("rows only", dict(want_final=True, want_anymatch=False)),
                   ("any-match only", dict(want_final=False, want_anymatch=True)), ("events only", dict(want_final=False, want_anymatch=False))):
