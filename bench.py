@@ -479,8 +479,8 @@ def main():
             mp.close()
             del d_m
         mix["slowdown"] = round(mix["one_in_64_trapped"]["kernel_ms_avg"] / mix["clean"]["kernel_ms_avg"], 3)
-        mix["note"] = ("snort_16 table + 222-state trap; the trapped streams (1.6 %) hold 222 states per pass and run on the "
-                       "wavefront-per-stream kernel behind the pack kernel; times are both launches together")
+        mix["note"] = ("snort_16 table + 222-state trap; the trapped streams (1.6 %) hold 222 states per pass and are finished behind "
+                       "the pack kernel, one workgroup per stream; times are both launches together")
         out["handoff_mix_T"] = mix
         tnfa.close()
 

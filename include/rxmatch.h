@@ -126,7 +126,8 @@ enum {
                              the pack kernel's choice and the two builds of RX_KERNEL_SYM_REG run the batch once,
                              timed, and the fastest is taken; up to 4 streams: always RX_KERNEL_SYM_REG            */
   RX_KERNEL_CSR_WAVE = 1, /* wavefront-per-stream over the state-major CSR exactly as loaded         */
-  RX_KERNEL_SYM_WAVE = 2, /* wavefront-per-stream over the per-(state,symbol) slice index            */
+  RX_KERNEL_SYM_WAVE = 2, /* wavefront-per-stream over the per-(state,symbol) slice index; also the kernel that finishes
+                             the streams the kernels below hand off (few of them: one workgroup per stream)   */
   RX_KERNEL_SYM_GROUP = 3, /* G lanes per stream (64/G streams per wavefront), slice index;
                              rx_opts.group_lanes = G (1/2/4/8/16, default 4); streams whose active set
                              outgrows the group's list are finished by RX_KERNEL_SYM_WAVE in the same call */

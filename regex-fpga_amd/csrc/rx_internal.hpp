@@ -39,7 +39,7 @@ static constexpr uint32_t RXE_TGT_MASK = 0x00FFFFFFu;
 // of LDS: 2*(size/8) + 1 KB <= 160 KB.  Larger automata are refused at load time, before any index is built.
 static constexpr uint32_t RX_MAX_STATES = 650000;
 static constexpr uint32_t RX_LIST_CAP = 128;  // sparse active-list capacity per stream (entries), at least
-static constexpr uint32_t RX_LIST_CAP_MAX = 1024;  // ... and at most (rx_pick_launch: what four wavefronts per block leave room for)
+static constexpr uint32_t RX_LIST_CAP_MAX = 512;  // ... and at most (rx_pick_launch: what four wavefronts per block leave room for)
 static constexpr uint32_t RX_SMALL_DEG = 8;   // CSR kernel: rows up to this length are scanned per lane
 
 // Kernel argument block (passed by value).

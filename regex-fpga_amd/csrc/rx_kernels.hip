@@ -396,6 +396,158 @@ __global__ void __launch_bounds__(256) rx_csr_wave_kernel(const RxParams p) {
 // =================================================================================================
 // Kernel 2: wavefront-per-stream over the per-(state, byte) slice index
 // =================================================================================================
+// ---- finishing hand-offs with the whole WORKGROUP on one stream (SURVEY §8 f2's variant: one stream's active states split
+// over the wavefronts of a workgroup) ---------------------------------------------------------------------------------
+// A stream that the pack / group / register kernels hand off holds more states than their lists take (the trap of
+// bench.py's handoff_mix_T: 222 per pass).  One wavefront alone walks such a set in four dependent sweeps per pass; here the
+// wavefronts of the block take every fourth sweep (list form) or every fourth group of 64 bitmask words (dense form) of the
+// SAME stream: the next set's dedup bitmask and list are shared (LDS atomics work across the wavefronts of a block), list
+// slots come from one LDS counter (one atomic per wavefront and insertion step), and two block barriers per pass separate
+// "everybody inserts" from "current <- next".  Used when few streams were handed off (RX_BLOCK_RESUME_MAX): with many, one
+// wavefront per stream fills the chip better.  Wave-uniform / block-uniform control flow throughout.
+static constexpr uint32_t RX_BLOCK_RESUME_MAX = 4096;
+
+__device__ __forceinline__ void resume_streams_by_block(const RxParams& p, uint32_t* lds, uint32_t total) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wib = tid >> 6, nthr = blockDim.x, nwav = blockDim.x >> 6;
+  const uint32_t cap = (p.lds_words_per_stream - 2u * p.nw32) >> 1;
+  uint32_t* cb = lds;                 // region of wavefront 0: the stream's two bitmasks and two lists
+  uint32_t* nb = cb + p.nw32;
+  uint32_t* clist = nb + p.nw32;
+  uint32_t* nlist = clist + cap;
+  uint32_t* ctrl = lds + p.lds_words_per_stream;  // (region of wavefront 1, unused here) [0],[1]: list counters of even / odd passes, [2]: any-match bits
+  const uint32_t* __restrict__ symidx = p.symidx;
+  const uint32_t* __restrict__ ovf = p.ovf;
+  for (uint32_t idx = blockIdx.x; idx < total; idx += gridDim.x) {  // (block-uniform)
+    const uint32_t stream = p.spill_streams[idx], k0 = p.spill_k[idx];
+    const uint32_t* row = p.spill_rows + (size_t)idx * p.nw64x2;
+    __syncthreads();  // the previous stream's final set has been stored
+    for (uint32_t w = tid; w < p.nw32; w += nthr) { cb[w] = row[w]; nb[w] = 0u; }
+    if (tid == 0) {
+      ctrl[0] = 0u;
+      ctrl[1] = 0u;
+      // the hand-off pass already emitted its accept pulses; keep the bits of its partial bitmap word
+      ctrl[2] = p.anymatch ? p.anymatch[(size_t)stream * p.anymatch_stride + (k0 >> 5)] : 0u;
+    }
+    bool dense = true;  // S_k arrives as a bitmask row
+    uint32_t n_cur = 0;
+    ByteFeed feed;
+    feed.base = p.bytes + (size_t)stream * p.stride;
+    feed.len = p.stream_len;
+    feed.aligned = ((reinterpret_cast<uintptr_t>(feed.base)) & 3u) == 0;
+    uint32_t cur_word = 0, nxt_word = feed.load_chunk(k0 >> 8, lane);  // (every wavefront keeps its own copy of the bytes)
+    __syncthreads();
+
+    for (uint32_t k = k0; k < p.n_passes; k++) {
+      const bool consume = k < p.n_consume;
+      const bool pulses = k != k0;
+      uint32_t* cnt = &ctrl[k & 1u];
+      uint32_t c = 0;
+      if (consume) {
+        if ((k & 255u) == 0 || k == k0) {
+          cur_word = nxt_word;
+          nxt_word = feed.load_chunk((k >> 8) + 1u, lane);
+        }
+        c = (bcast(cur_word, (k >> 2) & 63u) >> ((k & 3u) * 8u)) & 0xFFu;
+      }
+      // insert one target per lane into the stream's next set; wave-uniform call
+      auto emit = [&](bool pred, uint32_t t) {
+        bool fresh = false;
+        if (pred) {
+          const uint32_t s = t & RXE_TGT_MASK;
+          const uint32_t bit = 1u << (s & 31u);
+          fresh = (atomicOr(&nb[s >> 5], bit) & bit) == 0u;
+        }
+        const uint64_t m = wballot(fresh);
+        if (m) {
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(cnt, (uint32_t)__popcll(m));
+          const uint32_t slot = bcast(base, 0) + rank_below(m);
+          if (fresh && slot < cap) nlist[slot] = t;
+        }
+      };
+      // up to one entry of S_k per lane: pulse, slice, insertions; wave-uniform call
+      auto step = [&](bool valid, uint32_t e) {
+        const uint32_t s = e & RXE_TGT_MASK;
+        const bool acc = valid && (e & RXE_ACCEPT);
+        if (pulses) {
+          uint32_t am = 0;
+          emit_events(p, acc, s, stream, k, lane, am);
+          if (am != 0u && lane == 0) atomicOr(&ctrl[2], am);
+        }
+        if (!consume) return;
+        const uint32_t ent = (valid && !acc) ? symidx[(size_t)s * 256u + c] : 0u;
+        if (wballot(ent & RXE_SELF)) emit((ent & RXE_SELF) != 0, s);
+        if (wballot(ent & RXE_INLINE)) emit((ent & RXE_INLINE) != 0, ent & (RXE_TGT_MASK | RXE_ACCEPT));
+        uint64_t mo = wballot(ent & RXE_OVF);
+        if (mo == 0ull) return;
+        const uint32_t mycnt = (ent & RXE_OVF) ? ovf[ent & RXE_TGT_MASK] : 0u;
+        while (mo) {
+          const uint32_t src = (uint32_t)__builtin_ctzll(mo);
+          mo &= mo - 1;
+          const uint32_t off = bcast(ent & RXE_TGT_MASK, src);
+          const uint32_t n = bcast(mycnt, src);
+          for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
+            const bool act = j0 + lane < n;
+            emit(act, act ? ovf[off + 1u + j0 + lane] : 0u);
+          }
+        }
+      };
+      const uint32_t w_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)wib) * 64u;  // (scalar for the compiler too)
+      if (!dense) {
+        for (uint32_t b = w_first; b < n_cur; b += nwav * 64u) {
+          const uint32_t i = b + lane;
+          step(i < n_cur, i < n_cur ? clist[i] : 0u);
+        }
+      } else {
+        for (uint32_t w0 = w_first; w0 < p.nw32; w0 += nwav * 64u) {
+          const uint32_t wi = w0 + lane;
+          const uint32_t word = wi < p.nw32 ? cb[wi] : 0u;
+          uint64_t m = wballot(word != 0u);
+          while (m) {
+            const uint32_t src = (uint32_t)__builtin_ctzll(m);
+            m &= m - 1;
+            const uint32_t wv = bcast(word, src);
+            const bool valid = lane < 32u && ((wv >> lane) & 1u);
+            uint32_t e = (w0 + src) * 32u + lane;
+            if (valid && ((p.accept_bits[e >> 5] >> (e & 31u)) & 1u)) e |= RXE_ACCEPT;
+            step(valid, e);
+          }
+        }
+      }
+      __syncthreads();  // every wavefront has inserted (and pulsed)
+      if (consume) {  // current <- next (FPGA.v:733-737)
+        const uint32_t n_next = *cnt;
+        if (dense)
+          for (uint32_t w = tid; w < p.nw32; w += nthr) cb[w] = 0u;
+        if (n_next > cap) {  // the bitmask is the set
+          uint32_t* t = cb; cb = nb; nb = t;
+          dense = true;
+          n_cur = 0;
+        } else {  // the list is the set: wipe the filter words it touched
+          for (uint32_t i = tid; i < n_next; i += nthr) nb[(nlist[i] & RXE_TGT_MASK) >> 5] = 0u;
+          uint32_t* t = clist; clist = nlist; nlist = t;
+          dense = false;
+          n_cur = n_next;
+        }
+      }
+      if (tid == 0) {
+        ctrl[(k + 1u) & 1u] = 0u;  // (nobody touches the other counter before the barrier below)
+        if (p.anymatch && ((k & 31u) == 31u || k + 1 == p.n_passes)) {
+          p.anymatch[(size_t)stream * p.anymatch_stride + (k >> 5)] = ctrl[2];
+          ctrl[2] = 0u;
+        }
+      }
+      __syncthreads();
+    }
+    if (wib == 0) {  // the final set, by one wavefront (the others wait at the top of the loop / leave)
+      StreamState st;
+      st.cb = cb; st.nb = nb; st.clist = clist; st.nlist = nlist;
+      st.n_cur = n_cur; st.n_next = 0; st.cap = cap; st.dense = dense;
+      stream_store_final(p, st, stream, lane);
+    }
+  }
+}
+
 template <bool STATS>
 __global__ void __launch_bounds__(256) rx_sym_wave_kernel(const RxParams p) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -412,6 +564,10 @@ __global__ void __launch_bounds__(256) rx_sym_wave_kernel(const RxParams p) {
   if (p.resume) {
     const unsigned long long n = *p.spill_count;
     total = n < p.n_streams ? (uint32_t)n : p.n_streams;
+    if (!STATS && wpb >= 2u && total <= RX_BLOCK_RESUME_MAX) {  // few hand-offs: the whole block on one stream at a time
+      resume_streams_by_block(p, lds, total);
+      return;
+    }
   }
 
   for (uint32_t idx = blockIdx.x * wpb + wib; idx < total; idx += gridDim.x * wpb) {
