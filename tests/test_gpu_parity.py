@@ -309,6 +309,26 @@ def test_handoff_in_the_middle_of_a_stream(rx, orx, kernels):
             check_equal(rx, orx, got, ref, ("late handoff", mode, kern, "plain"), stats=False)
 
 
+def test_many_handoffs_take_one_wavefront_per_stream(rx, orx):
+    """More handed-off streams than the workgroup-per-stream form of the finishing launch takes (4 096): that launch falls
+    back to one wavefront per stream.  5 000 streams, every one of them outgrows the pack kernel's list."""
+    W, size = late_blowup_nfa(220)
+    nfa = rx.Nfa.from_words(W)
+    base = b"xabxab..abYab"
+    rows = np.zeros((5000, 48), np.uint8)
+    for s in range(5000):
+        txt = bytearray((base * 4)[:48])
+        at = 3 + (s * 7) % 30
+        txt[at:at + 6] = b"ZYYBab"
+        rows[s] = np.frombuffer(bytes(txt), np.uint8)
+    ref = orx.match_batch(W, size, rows, want_match_count=False)
+    assert ref["stats"]["max_active"] > 200
+    for kern in (dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=13), dict(kernel=rx.KERNEL_SYM_PACK, group_lanes=16, flags=rx.host.OPT_FORCE_FOLD),
+                 dict(kernel=rx.KERNEL_SYM_GROUP, group_lanes=4)):
+        got = rx.match(nfa, rows, **kern)
+        check_equal(rx, orx, got, ref, ("many hand-offs", kern), stats=False)
+
+
 def test_random_automata(rx, orx, kernels):
     """Seeded random NFAs (unsorted rows, multi-target symbols, self loops, sinks) x random streams."""
     rng = np.random.default_rng(20261004)
