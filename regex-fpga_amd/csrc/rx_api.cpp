@@ -369,6 +369,12 @@ struct rx_plan {
   uint32_t* d_final = nullptr;
   // rx_plan_run, compact final sets (on request): states per block of streams, offset / count per stream
   uint32_t* d_fstates = nullptr;
+  // rx_plan_run: page-locked staging for the two downloads whose sizes are only known once the counters are on the host
+  // (accept events, compact final lists); grown on demand
+  void* h_stage_ev = nullptr;
+  size_t h_stage_ev_bytes = 0;
+  void* h_stage_fs = nullptr;
+  size_t h_stage_fs_bytes = 0;
   uint32_t *d_foff = nullptr, *d_fcnt = nullptr;
   size_t fstates_cap = 0;
   uint32_t* d_init = nullptr;
@@ -522,6 +528,8 @@ extern "C" void rx_plan_free(rx_plan* p) {
   (void)hipFree(p->d_am);
   (void)hipFree(p->d_final);
   (void)hipFree(p->d_fstates);
+  if (p->h_stage_ev) (void)hipHostFree(p->h_stage_ev);
+  if (p->h_stage_fs) (void)hipHostFree(p->h_stage_fs);
   (void)hipFree(p->d_foff);
   (void)hipFree(p->d_fcnt);
   (void)hipFree(p->d_init);
@@ -1226,6 +1234,40 @@ static bool ev_less(const rx_event& a, const rx_event& b) {
 // arrival order — per stream already ascending in k (a wavefront's passes allocate their slots one after the other) —
 // so a stable counting sort by stream does nearly everything in O(n); an insertion sort per stream finishes equal-k
 // runs and anything an unusual kernel left out of order.  (std::sort on 75 000 events took 5 ms of a 8 ms call.)
+// `src` (device order) -> `dst` in (stream, k, state) order; the two may not overlap
+static void sort_events_into(const rx_event* src, rx_event* dst, size_t n, uint32_t lo, size_t n_streams) {
+  if (n == 0) return;
+  bool ok = n >= 64 && n_streams <= 8 * n + 1024;
+  std::vector<uint32_t> at;
+  if (ok) {
+    at.assign(n_streams + 1, 0u);
+    for (size_t i = 0; i < n && ok; i++) {
+      const rx_event& e = src[i];
+      if (e.stream < lo || e.stream - lo >= n_streams) ok = false;  // not ours: be safe
+      else at[e.stream - lo + 1]++;
+    }
+  }
+  if (!ok) {
+    memcpy(dst, src, n * sizeof(rx_event));
+    std::sort(dst, dst + n, ev_less);
+    return;
+  }
+  for (size_t i = 0; i < n_streams; i++) at[i + 1] += at[i];
+  {
+    std::vector<uint32_t> pos(at.begin(), at.end() - 1);
+    for (size_t i = 0; i < n; i++) dst[pos[src[i].stream - lo]++] = src[i];
+  }
+  for (size_t st = 0; st < n_streams; st++) {
+    const uint32_t b = at[st], e = at[st + 1];
+    for (uint32_t i = b + 1; i < e; i++) {
+      const rx_event x = dst[i];
+      uint32_t j = i;
+      while (j > b && ev_less(x, dst[j - 1])) { dst[j] = dst[j - 1]; j--; }
+      dst[j] = x;
+    }
+  }
+}
+
 static void sort_events(rx_event* ev, size_t n, uint32_t lo, size_t n_streams, std::vector<rx_event>& scratch) {
   if (n < 2) return;
   if (n < 64 || n_streams > 8 * n + 1024) { std::sort(ev, ev + n, ev_less); return; }
@@ -1640,29 +1682,67 @@ static int plan_run_body(rx_plan* p, const uint8_t* bytes, size_t n_streams, siz
   st.n_events = ev_total;
   if (ev_total > p->events_cap && res->events) res->events_overflow = 1u;
   const size_t captured = (size_t)std::min<unsigned long long>(ev_total, p->events_cap);
-  if (res->events && res->events_cap && captured) {
-    // the device buffer holds the blocks' events back to back in launch order (the first `captured` slots); each block's
-    // part is brought into (stream, k, state) order on its own
-    std::vector<rx_event> tmp(captured), scratch;
-    HIPCHK(hipMemcpy(tmp.data(), p->d_events, captured * sizeof(rx_event), hipMemcpyDeviceToHost));
-    for (size_t b = 0; b < n_blocks; b++) {
-      const size_t lo = (size_t)std::min<unsigned long long>(b ? ev_after[b - 1] : 0ull, captured);
-      const size_t hi = (size_t)std::min<unsigned long long>(ev_after[b], captured);
-      if (hi > lo) sort_events(tmp.data() + lo, hi - lo, (uint32_t)(b * per), std::min(per, n_streams - b * per), scratch);
-    }
-    const size_t n = std::min(captured, res->events_cap);
-    memcpy(res->events, tmp.data(), n * sizeof(rx_event));
-    res->n_events = n;
-    if (n < captured) res->events_overflow = 1u;
-  }
+  // The two downloads whose sizes the host has only now: both go out together, into page-locked staging (a blocking copy
+  // into the caller's pageable arrays, one after the other, was 0.3 of the 2.5 ms of a configs[2] call); the events are put
+  // into order on their way from the staging buffer to the caller's array.
+  auto stage = [](void** buf, size_t* have, size_t need) -> int {
+    if (need <= *have) return RX_OK;
+    if (*buf) (void)hipHostFree(*buf);
+    *buf = nullptr;
+    *have = 0;
+    const size_t want = need + need / 2;
+    HIPCHK(hipHostMalloc(buf, want, hipHostMallocDefault));
+    *have = want;
+    return RX_OK;
+  };
+  const bool ev_down = res->events && res->events_cap && captured;
+  size_t fs_n = 0;
   if (compact) {
     // (final_off is a position in final_states; a set that did not fit wholly is cut at the capacity, final_cnt stays exact)
     const unsigned long long needed = p->h_run_ctr[1];
-    const size_t have_n = (size_t)std::min<unsigned long long>(needed, res->final_states_cap);
+    fs_n = (size_t)std::min<unsigned long long>(needed, res->final_states_cap);
     res->final_states_overflow = needed > res->final_states_cap ? 1u : 0u;
-    if (have_n) HIPCHK(hipMemcpy(res->final_states, p->d_fstates, have_n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    res->n_final_states = have_n;
+    res->n_final_states = fs_n;
   }
+  if (ev_down) {
+    if ((rc = stage(&p->h_stage_ev, &p->h_stage_ev_bytes, captured * sizeof(rx_event)))) return rc;
+    HIPCHK(hipMemcpyAsync(p->h_stage_ev, p->d_events, captured * sizeof(rx_event), hipMemcpyDeviceToHost, p->s_out));
+  }
+  if (fs_n) {
+    if ((rc = stage(&p->h_stage_fs, &p->h_stage_fs_bytes, fs_n * sizeof(uint32_t)))) return rc;
+    HIPCHK(hipMemcpyAsync(p->h_stage_fs, p->d_fstates, fs_n * sizeof(uint32_t), hipMemcpyDeviceToHost, p->s_in));
+  }
+  if (ev_down) {
+    HIPCHK(hipStreamSynchronize(p->s_out));
+    // the device buffer holds the blocks' events back to back in launch order (the first `captured` slots); each block's
+    // part is brought into (stream, k, state) order on its own (blocks are in stream order: the concatenation is sorted)
+    const rx_event* src = static_cast<const rx_event*>(p->h_stage_ev);
+    const size_t n = std::min(captured, res->events_cap);
+    if (n == captured) {
+      for (size_t b = 0; b < n_blocks; b++) {
+        const size_t lo = (size_t)std::min<unsigned long long>(b ? ev_after[b - 1] : 0ull, captured);
+        const size_t hi = (size_t)std::min<unsigned long long>(ev_after[b], captured);
+        if (hi > lo) sort_events_into(src + lo, res->events + lo, hi - lo, (uint32_t)(b * per), std::min(per, n_streams - b * per));
+      }
+    } else {  // the caller's array is shorter than what was captured: order everything, hand over the first n
+      std::vector<rx_event> tmp(src, src + captured), scratch;
+      for (size_t b = 0; b < n_blocks; b++) {
+        const size_t lo = (size_t)std::min<unsigned long long>(b ? ev_after[b - 1] : 0ull, captured);
+        const size_t hi = (size_t)std::min<unsigned long long>(ev_after[b], captured);
+        if (hi > lo) sort_events(tmp.data() + lo, hi - lo, (uint32_t)(b * per), std::min(per, n_streams - b * per), scratch);
+      }
+      memcpy(res->events, tmp.data(), n * sizeof(rx_event));
+      res->events_overflow = 1u;
+    }
+    res->n_events = n;
+  }
+  if (fs_n) {
+    HIPCHK(hipStreamSynchronize(p->s_in));
+    memcpy(res->final_states, p->h_stage_fs, fs_n * sizeof(uint32_t));
+  }
+  if (verbose)
+    fprintf(stderr, "[rxmatch] run: events and final lists on the host %.3f ms after the last enqueue\n",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w_issued).count());
   if (p->cfg.stats) {
     st.alg_bytes = (uint64_t)p->params.n_consume * n_streams + 8 * st.sum_active + 4 * st.sum_edges +
                    (uint64_t)n_streams * ((st.n_passes + 7) / 8) + 12 * st.n_events;
